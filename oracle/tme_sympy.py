@@ -1,0 +1,228 @@
+"""Taylor moment expansion (TME) by SymPy differentiation (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+Restates the published algorithm of the third-party package the reference calls (`tme.base_jax`, PyPI `tme>=0.1.5`,
+not vendored in /root/reference; requirements.txt:6) at the reference's call sites:
+
+  tme.expectation(phi, x, dt, drift, dispersion, order)   mfs/one_dim/moments.py:151,159,167,171,211;
+                                                          mfs/multi_dims/moments.py:403,451,459,467,471
+  tme.mean_and_cov(x, dt, drift, dispersion, order)       mfs/one_dim/moments.py:175,190,197,204,215;
+                                                          mfs/multi_dims/moments.py:379,387,395,407,475
+
+Mathematics (Zhao, Karvonen, Hostettler, Sarkka, "Taylor moment expansion for continuous-discrete Gaussian
+filtering", IEEE TAC 2021, eqs. (9), (14)-(16)):
+
+  generator      A phi = sum_i a_i d_i phi + 1/2 sum_ij (b b^T)_ij d_i d_j phi
+  expectation    E[phi(X_{t+dt}) | x] ~= sum_{r=0}^{M} dt^r / r! A^r phi(x)
+  mean           the expectation of the identity
+  cov            sum_{r=1}^{M} dt^r / r! [ A^r(x x^T) - sum_{s=0}^{r} C(r, s) A^s x (A^{r-s} x)^T ]
+                 (truncated in powers of dt; NOT E[x x^T]_M - m_M m_M^T)
+
+Where JAX differentiates a traced program, this file differentiates SymPy expressions; the arithmetic then runs in
+NumPy fp64 through `lambdify`.  It is deliberately a different derivation engine from the product's
+polynomial-ring generator (mfs_amd/tme_poly.py) so that the two check each other.
+"""
+import math
+from typing import Callable, Sequence
+
+import numpy as np
+import sympy as sp
+
+
+def generator(phi: sp.Expr, xs: Sequence[sp.Symbol], drift: Sequence[sp.Expr], gamma: sp.Matrix) -> sp.Expr:
+    """A phi for an Ito SDE with drift vector `drift` and diffusion matrix gamma = b b^T."""
+    out = 0
+    for i, xi in enumerate(xs):
+        out += drift[i] * sp.diff(phi, xi)
+    for i, xi in enumerate(xs):
+        for j, xj in enumerate(xs):
+            if gamma[i, j] != 0:
+                out += sp.Rational(1, 2) * gamma[i, j] * sp.diff(phi, xi, xj)
+    return out
+
+
+def generator_powers(phi: sp.Expr, xs, drift, gamma, order: int):
+    """[phi, A phi, ..., A^order phi]."""
+    out = [phi]
+    for _ in range(order):
+        out.append(generator(out[-1], xs, drift, gamma))
+    return out
+
+
+def expectation_expr(phi: sp.Expr, xs, drift, gamma, dt, order: int) -> sp.Expr:
+    """sum_{r<=order} dt^r / r! A^r phi."""
+    pows = generator_powers(phi, xs, drift, gamma, order)
+    return sum(sp.Float(dt) ** r / math.factorial(r) * pows[r] for r in range(order + 1))
+
+
+def mean_and_cov_expr(xs, drift, gamma, dt, order: int):
+    """(mean vector, covariance matrix) expressions, truncated in powers of dt as `tme.mean_and_cov` does."""
+    d = len(xs)
+    Ai = [generator_powers(xs[i], xs, drift, gamma, order) for i in range(d)]
+    mean = [sum(sp.Float(dt) ** r / math.factorial(r) * Ai[i][r] for r in range(order + 1)) for i in range(d)]
+    cov = sp.zeros(d, d)
+    for i in range(d):
+        for j in range(i, d):
+            Aij = generator_powers(xs[i] * xs[j], xs, drift, gamma, order)
+            c = 0
+            for r in range(1, order + 1):
+                coeff = Aij[r]
+                for s in range(r + 1):
+                    coeff -= math.comb(r, s) * Ai[i][s] * Ai[j][r - s]
+                c += sp.Float(dt) ** r / math.factorial(r) * coeff
+            cov[i, j] = c
+            cov[j, i] = c
+    return mean, cov
+
+
+def _sym_model_1d(drift: Callable, dispersion: Callable):
+    x = sp.Symbol('x', real=True)
+    a = sp.sympify(drift(x))
+    b = sp.sympify(dispersion(x))
+    return x, [a], sp.Matrix([[b * b]])
+
+
+def _lambdify(args, expr):
+    f = sp.lambdify(args, expr, modules='numpy')
+
+    def g(*vals):
+        with np.errstate(all='ignore'):
+            out = f(*vals)
+        shape = np.broadcast(*[np.asarray(v) for v in vals]).shape
+        return np.broadcast_to(np.asarray(out, dtype=np.float64), shape).copy()
+
+    return g
+
+
+def sde_cond_moments_tme_1d(drift: Callable, dispersion: Callable, dt: float, tme_order: int, num_moments: int):
+    """The five closures of mfs/one_dim/moments.py:141-179 for orders 0..num_moments-1.
+
+    `drift`/`dispersion` must accept a SymPy symbol (e.g. `lambda x: sympy.tanh(x)`).
+    Returns (cond_rms(x, n), cond_cms(x, n, mean), cond_scms(x, n, mean, scale), cond_mean(x), cond_mean_var(x)).
+    """
+    x, a, gam = _sym_model_1d(drift, dispersion)
+    c = sp.Symbol('c', real=True)
+    fns = []
+    for n in range(num_moments):
+        e = expectation_expr((x - c) ** n, [x], a, gam, dt, tme_order)
+        fns.append(_lambdify((x, c), e))
+    mean_e, cov_e = mean_and_cov_expr([x], a, gam, dt, tme_order)
+    mean_f = _lambdify((x,), mean_e[0])
+    var_f = _lambdify((x,), cov_e[0, 0])
+
+    def cond_cms(xs, ns, mean):
+        xs = np.asarray(xs, dtype=np.float64)
+        return np.stack([fns[int(n)](xs, mean) for n in ns], axis=-1)
+
+    def cond_rms(xs, ns):
+        return cond_cms(xs, ns, 0.)
+
+    def cond_scms(xs, ns, mean, scale):
+        return cond_cms(xs, ns, mean) / scale ** np.asarray(ns, dtype=np.float64)
+
+    def cond_mean(xs):
+        return mean_f(np.asarray(xs, dtype=np.float64))
+
+    def cond_mean_var(xs):
+        xs = np.asarray(xs, dtype=np.float64)
+        return mean_f(xs), var_f(xs)
+
+    return cond_rms, cond_cms, cond_scms, cond_mean, cond_mean_var
+
+
+def gaussian_closure_1d(cond_mean_var: Callable, num_moments: int):
+    """Normal-approximation closures given (mean, var)(x): mfs/one_dim/moments.py:186-199 / :225-237.
+
+    The scaled variant divides by scale**n (the mathematically intended normalisation); the reference's
+    `jnp.prod(scale ** arange(num_moments))` at :205-207 / :243-244 is an untested quirk and is not
+    replicated.
+    """
+    from oracle.one_dim import raw_moment_of_normal
+
+    def cond_cms(xs, ns, mean):
+        m, v = cond_mean_var(np.asarray(xs, dtype=np.float64))
+        allp = np.stack([raw_moment_of_normal(m - mean, v, p) for p in range(num_moments)], axis=-1)
+        return allp[..., np.asarray(ns, dtype=int)]
+
+    def cond_rms(xs, ns):
+        return cond_cms(xs, ns, 0.)
+
+    def cond_scms(xs, ns, mean, scale):
+        return cond_cms(xs, ns, mean) / scale ** np.asarray(ns, dtype=np.float64)
+
+    def cond_mean(xs):
+        return cond_mean_var(xs)[0]
+
+    return cond_rms, cond_cms, cond_scms, cond_mean, cond_mean_var
+
+
+def sde_cond_moments_tme_normal_1d(drift, dispersion, dt, tme_order, N):
+    """mfs/one_dim/moments.py:182-219."""
+    x, a, gam = _sym_model_1d(drift, dispersion)
+    mean_e, cov_e = mean_and_cov_expr([x], a, gam, dt, tme_order)
+    mean_f, var_f = _lambdify((x,), mean_e[0]), _lambdify((x,), cov_e[0, 0])
+
+    def cond_mean_var(xs):
+        xs = np.asarray(xs, dtype=np.float64)
+        return mean_f(xs), var_f(xs)
+
+    return gaussian_closure_1d(cond_mean_var, 2 * N)
+
+
+def sde_cond_moments_euler_1d(drift, dispersion, dt, N):
+    """mfs/one_dim/moments.py:222-255 (drift/dispersion given as SymPy-compatible callables)."""
+    x, a, gam = _sym_model_1d(drift, dispersion)
+    mean_f, var_f = _lambdify((x,), x + a[0] * sp.Float(dt)), _lambdify((x,), gam[0, 0] * sp.Float(dt))
+
+    def cond_mean_var(xs):
+        xs = np.asarray(xs, dtype=np.float64)
+        return mean_f(xs), var_f(xs)
+
+    return gaussian_closure_1d(cond_mean_var, 2 * N)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N-D (mfs/multi_dims/moments.py:414-479): phi = prod_k ((x_k - m_k) / r_k)^{n_k}
+# ---------------------------------------------------------------------------------------------------------------------
+def sde_cond_moments_tme_nd(drift: Callable, dispersion: Callable, d: int, dt: float, tme_order: int,
+                            multi_indices: np.ndarray):
+    """Closures of mfs/multi_dims/moments.py:414-479 for a fixed table of multi-indices ('multi-index' signature).
+
+    `drift(xs)` takes a list of d SymPy symbols and returns d expressions; `dispersion(xs)` returns a d x w matrix
+    (nested lists).  Returns (cond_rms(x, mi), cond_cms(x, mi, mean), cond_mean(x), cond_mean_var(x)).
+    """
+    xs = sp.symbols(f'x0:{d}', real=True)
+    cs = sp.symbols(f'c0:{d}', real=True)
+    a = [sp.sympify(e) for e in drift(list(xs))]
+    b = sp.Matrix(dispersion(list(xs)))
+    gam = b * b.T
+    table = {}
+    for mi in np.asarray(multi_indices):
+        key = tuple(int(v) for v in mi)
+        phi = sp.Integer(1)
+        for k in range(d):
+            phi *= (xs[k] - cs[k]) ** key[k]
+        table[key] = _lambdify((*xs, *cs), expectation_expr(phi, xs, a, gam, dt, tme_order))
+    mean_e, cov_e = mean_and_cov_expr(xs, a, gam, dt, tme_order)
+    mean_f = [_lambdify(tuple(xs), e) for e in mean_e]
+    var_f = [_lambdify(tuple(xs), cov_e[i, i]) for i in range(d)]
+
+    def cond_cms(x, mis, mean):
+        x = np.asarray(x, dtype=np.float64)
+        cols = [x[..., k] for k in range(d)]
+        mean = np.broadcast_to(np.asarray(mean, dtype=np.float64), (d,))
+        return np.stack([table[tuple(int(v) for v in mi)](*cols, *mean) for mi in np.asarray(mis)], axis=-1)
+
+    def cond_rms(x, mis):
+        return cond_cms(x, mis, np.zeros(d))
+
+    def cond_mean(x):
+        x = np.asarray(x, dtype=np.float64)
+        cols = [x[..., k] for k in range(d)]
+        return np.stack([f(*cols) for f in mean_f], axis=-1)
+
+    def cond_mean_var(x):
+        x = np.asarray(x, dtype=np.float64)
+        cols = [x[..., k] for k in range(d)]
+        return cond_mean(x), np.stack([f(*cols) for f in var_f], axis=-1)
+
+    return cond_rms, cond_cms, cond_mean, cond_mean_var
