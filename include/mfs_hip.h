@@ -1,0 +1,188 @@
+/*
+ * mfs_hip.h -- C ABI of libmfs_hip.so: the MI355X (gfx950) moment-filter hot path of zgbkdlm/mfs.
+ *
+ * This is the drop-in boundary.  The reference is pure Python/JAX and has no FFI of its own; the entry points
+ * below are what a ctypes binding for its filter loop binds (INTEGRATION.md shows the stub).  Each entry point
+ * names the reference interface it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; all floating point is IEEE fp64 (the reference sets jax_enable_x64).
+ *   - every function returns MFS_OK (0) or a negative MFS_E* code; mfs_last_error() gives the message of the
+ *     calling thread's last failure.  Numerical failure is NEVER an error code: a non-positive-definite moment
+ *     matrix poisons that replicate with NaN in-band, exactly as the reference's XLA Cholesky does, and the first
+ *     poisoned step is reported in out_first_nan.
+ *   - "host" entry points take host pointers and stage through device buffers owned by the library;
+ *     "_dev" entry points take device pointers (inputs already resident in HBM) and only enqueue work on `stream`.
+ *   - batch axis: B independent replicates (Monte-Carlo keys / parameter points; the reference runs these as
+ *     separate calls, dardel/benes_bernoulli/mf.py:70-92).  Layouts are row-major with the replicate axis first.
+ */
+#ifndef MFS_HIP_H
+#define MFS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFS_ABI_VERSION 1
+
+/* return codes */
+#define MFS_OK 0
+#define MFS_EINVAL (-1)   /* bad argument (mirrors the reference's only raise, multi_dims/filtering.py:159-161) */
+#define MFS_EUNSUPPORTED (-2) /* N / degree / model outside what the kernels are compiled for */
+#define MFS_EHIP (-3)     /* a HIP runtime call failed (message in mfs_last_error) */
+#define MFS_ENOMEM (-4)
+#define MFS_ERCCL (-5)
+
+/* moment representation, mfs/one_dim/filtering.py:32 / :92 / :164 */
+#define MFS_MODE_RAW 0
+#define MFS_MODE_CENTRAL 1
+#define MFS_MODE_SCALED 2
+
+/* how the transition moments E[(X_k - c)^n | X_{k-1} = x] are produced on the device */
+#define MFS_TRANS_OPERATOR 0 /* TME without closure: sum_{k<=K} Q_k(u(x)) n!/(n-k)! (x - c)^(n-k);
+                                replaces sde_cond_moments_tme, mfs/one_dim/moments.py:141-179 */
+#define MFS_TRANS_GAUSSIAN 1 /* normal closure from (mu(x), var(x)): TME-normal (:182-219), Euler (:222-255), or an
+                                exact linear-Gaussian step (dardel/convergence/convergence_mf.py:86-107) */
+
+/* the variable the coefficient tables are polynomials in */
+#define MFS_U_IDENTITY 0 /* u = x        (polynomial drift, e.g. well_poisson, OU) */
+#define MFS_U_TANH 1     /* u = tanh(x)  (benes_bernoulli, mfs/one_dim/ss_models.py:37-38) */
+
+/* measurement likelihood p(y | x) */
+#define MFS_LIK_BERNOULLI_LOGISTIC 0 /* p = 1/(1+exp(-(l0 + l1 x + l2 x^2 + l3 x^3))), pmf(y; p), y in {0,1}
+                                        (ss_models.py:43-47; multi_dims/ss_models.py:63-67 on x_0) */
+#define MFS_LIK_POISSON_SOFTPLUS 1   /* rate = log(1 + exp(l0 x)), Poisson pmf(y; rate) (ss_models.py:80-84) */
+#define MFS_LIK_GAUSSIAN 2           /* y ~ N(l0 x + l1, l2) (l2 = variance) (convergence_mf.py:58-61) */
+
+#define MFS_MAX_N 32       /* quadrature order N (2N moments) */
+#define MFS_MAX_TERMS 8    /* K <= 2 * tme_order */
+#define MFS_MAX_DEGREE 15  /* polynomial degree of a coefficient row */
+#define MFS_MAX_LIK 4
+
+/*
+ * 1-D model descriptor.  Replaces the Python callables the reference's filters take
+ * (state_cond_*_moments, state_cond_mean[_var], measurement_cond_pdf; mfs/one_dim/filtering.py:32-36,92-98,164-172):
+ * callables cannot cross a C ABI, so the host side reduces a model to coefficient tables (mfs_amd/tme_poly.py).
+ *
+ * coef is [n_rows][degree + 1] (ascending powers of u), or [B][n_rows][degree + 1] when coef_batched:
+ *   MFS_TRANS_OPERATOR: rows 0..K-1 = Q_1..Q_K (Q_0 = 1 is implicit); row K = conditional variance polynomial
+ *                       (tme.mean_and_cov, used by the scaled mode only).  Conditional mean = x + Q_1(u).
+ *                       n_rows = K + 1.
+ *   MFS_TRANS_GAUSSIAN: row 0 = P_m, row 1 = P_v with mu(x) = mean_x_coef * x + P_m(u), var(x) = P_v(u).
+ *                       n_rows = 2.
+ */
+typedef struct mfs_model_1d {
+    int32_t trans_kind;   /* MFS_TRANS_* */
+    int32_t umap;         /* MFS_U_* */
+    int32_t n_terms;      /* K (MFS_TRANS_OPERATOR); 0 otherwise */
+    int32_t degree;       /* J <= MFS_MAX_DEGREE */
+    int32_t n_rows;       /* rows per table */
+    int32_t coef_batched; /* 0: one table for all replicates; 1: one per replicate */
+    int32_t lik_kind;     /* MFS_LIK_* */
+    int32_t n_lik;        /* <= MFS_MAX_LIK */
+    int32_t lik_batched;  /* 0 / 1 */
+    int32_t reserved;
+    double mean_x_coef;   /* MFS_TRANS_GAUSSIAN only */
+    const double* coef;
+    const double* lik;    /* [n_lik] or [B][n_lik] */
+} mfs_model_1d;
+
+/* ---- library / device management --------------------------------------------------------------------------- */
+int mfs_version(void);                 /* MFS_ABI_VERSION */
+const char* mfs_last_error(void);      /* thread-local message of the last failing call ("" if none) */
+int mfs_device_count(int* count);
+int mfs_set_device(int device);
+int mfs_device_synchronize(void);
+int mfs_device_name(int device, char* buf, int buflen);
+
+/* device memory and streams for callers that keep data resident (bench harness, sharded driver) */
+int mfs_malloc(void** dptr, uint64_t bytes);
+int mfs_free(void* dptr);
+int mfs_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream);
+int mfs_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream);
+int mfs_memset(void* dst, int value, uint64_t bytes, void* stream);
+int mfs_stream_create(void** stream);
+int mfs_stream_destroy(void* stream);
+int mfs_stream_synchronize(void* stream);
+/* HIP-event timing on `stream` (bench.py's live per-launch kernel time) */
+int mfs_event_create(void** event);
+int mfs_event_destroy(void* event);
+int mfs_event_record(void* event, void* stream);
+int mfs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+
+/*
+ * ---- 1-D moment filter, host pointers ------------------------------------------------------------------------
+ * Replaces moment_filter_rms / moment_filter_cms / moment_filter_scms (mfs/one_dim/filtering.py:32-89, 92-161,
+ * 164-240) for B replicates at once.
+ *
+ *   mode        MFS_MODE_*
+ *   N           quadrature order; the moment vectors have 2N entries (orders 0..2N-1), 2 <= N <= MFS_MAX_N
+ *   T, B        time steps, replicates
+ *   m0          initial moments, [2N] (m0_batched = 0) or [B][2N]
+ *   mean0       [1] or [B] (same batching as m0); ignored in raw mode (may be NULL)
+ *   scale0      likewise; scaled mode only
+ *   ys          [B][T], measurements as doubles (Bernoulli y in {0., 1.})
+ *   stable      0 = Cholesky; 1 = LDL^T completion (mfs/utils.py:495-538)
+ *   out_moments [B][T][2N]   out_means [B][T] (NULL in raw mode)   out_scales [B][T] (scaled mode, else NULL)
+ *   out_nell    [B]          out_first_nan [B]: first step whose outputs are non-finite, -1 if none (may be NULL)
+ *   device      HIP device ordinal; stream: hipStream_t or NULL (default stream).  Returns after the results are
+ *               in the host buffers.
+ */
+int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B,
+                  const double* m0, int m0_batched, const double* mean0, const double* scale0,
+                  const double* ys, int stable,
+                  double* out_moments, double* out_means, double* out_scales, double* out_nell,
+                  int32_t* out_first_nan, int device, void* stream);
+
+/*
+ * ---- 1-D moment filter, device-resident plan -----------------------------------------------------------------
+ * The same computation with every buffer already in HBM.  A plan uploads the model tables once, owns the carry
+ * state, splits T into chunks of `chunk` steps (0 = whole T in one launch) and captures the chunk launches into a
+ * hipGraph so that a run is one graph launch.  All pointers passed to mfs_plan_1d_run are DEVICE pointers with the
+ * layouts documented for mfs_filter_1d; out_moments may be NULL ("NLL only", the parameter-estimation grid of
+ * dardel/parameter_estimation/mf.py:37-54 needs nothing else).
+ */
+typedef struct mfs_plan_1d mfs_plan_1d;
+
+int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model /* host pointers inside */, int mode, int N,
+                       int T, int B, int stable, int chunk, int device);
+int mfs_plan_1d_run(mfs_plan_1d* plan, const double* d_m0, int m0_batched, const double* d_mean0,
+                    const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
+                    double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream);
+int mfs_plan_1d_destroy(mfs_plan_1d* plan);
+/* launch geometry actually used (for DESIGN.md / the bench JSON): lanes per filter, filters per block, grid size */
+int mfs_plan_1d_geometry(const mfs_plan_1d* plan, int* lanes_per_filter, int* filters_per_block, int* grid,
+                         int* lds_bytes_per_block);
+
+/*
+ * ---- quadrature only -----------------------------------------------------------------------------------------
+ * Replaces moment_quadrature (mfs/one_dim/quadtures.py:83-133) for B moment vectors: ms [B][2N], mean/scale [B] or
+ * NULL (0 / 1), out weights/nodes [B][N].  Host pointers.  Used by the parity tests to check the Cholesky /
+ * triangular-solve / eigensolve stage in isolation, and by characteristic-function post-processing
+ * (mfs/one_dim/moments.py:309-337).
+ */
+int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const double* scale, int stable,
+                      double* out_weights, double* out_nodes, int device, void* stream);
+
+/*
+ * ---- multi-GPU: one process per GPU, replicates sharded, NLL all-gather over RCCL / xGMI -----------------------
+ * The reference has no multi-device code (its Monte-Carlo runs are separate OS processes,
+ * dardel/run_benes_bernoulli_mf.sh:26-31); replicates share nothing, so the data path needs no collective and the
+ * only exchange is one ncclAllGather of the per-replicate negative log-likelihoods after the kernel
+ * (SURVEY.md section 8e).  Rank 0 creates an id, the host side distributes its 128 bytes by any means
+ * (mfs_amd/dist.py uses torch.distributed's store), every rank calls mfs_comm_init.
+ */
+typedef struct mfs_rccl_id { char bytes[128]; } mfs_rccl_id; /* = ncclUniqueId */
+int mfs_comm_unique_id(mfs_rccl_id* id);
+int mfs_comm_init(void** comm, const mfs_rccl_id* id, int nranks, int rank, int device);
+/* d_send [count], d_recv [nranks * count], DEVICE pointers, rank-major; enqueued on `stream` */
+int mfs_allgather_nell(void* comm, const double* d_send, double* d_recv, uint64_t count, void* stream);
+int mfs_comm_destroy(void* comm);
+int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFS_HIP_H */

@@ -1,0 +1,150 @@
+"""ctypes binding of libmfs_hip.so (C ABI: include/mfs_hip.h).  There is no CPU fallback: a missing library raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmfs_hip.so')
+
+MFS_OK = 0
+MODE = {'raw': 0, 'central': 1, 'scaled': 2}
+TRANS = {'operator': 0, 'gaussian': 1}
+UMAP = {'x': 0, 'tanh': 1}
+LIK = {'bernoulli_logistic': 0, 'poisson_softplus': 1, 'gaussian': 2}
+MAX_N = 32
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class MfsModel1d(C.Structure):
+    """struct mfs_model_1d (include/mfs_hip.h)."""
+    _fields_ = [('trans_kind', C.c_int32), ('umap', C.c_int32), ('n_terms', C.c_int32), ('degree', C.c_int32),
+                ('n_rows', C.c_int32), ('coef_batched', C.c_int32), ('lik_kind', C.c_int32), ('n_lik', C.c_int32),
+                ('lik_batched', C.c_int32), ('reserved', C.c_int32), ('mean_x_coef', C.c_double),
+                ('coef', c_double_p), ('lik', c_double_p)]
+
+
+class MfsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/mfs_hip.h declares: (name, restype, argtypes)
+_vp, _vpp, _i, _u64 = C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint64
+_SIGNATURES = [
+    ('mfs_version', _i, []),
+    ('mfs_last_error', C.c_char_p, []),
+    ('mfs_device_count', _i, [C.POINTER(C.c_int)]),
+    ('mfs_set_device', _i, [_i]),
+    ('mfs_device_synchronize', _i, []),
+    ('mfs_device_name', _i, [_i, C.c_char_p, _i]),
+    ('mfs_malloc', _i, [_vpp, _u64]),
+    ('mfs_free', _i, [_vp]),
+    ('mfs_memcpy_h2d', _i, [_vp, _vp, _u64, _vp]),
+    ('mfs_memcpy_d2h', _i, [_vp, _vp, _u64, _vp]),
+    ('mfs_memset', _i, [_vp, _i, _u64, _vp]),
+    ('mfs_stream_create', _i, [_vpp]),
+    ('mfs_stream_destroy', _i, [_vp]),
+    ('mfs_stream_synchronize', _i, [_vp]),
+    ('mfs_event_create', _i, [_vpp]),
+    ('mfs_event_destroy', _i, [_vp]),
+    ('mfs_event_record', _i, [_vp, _vp]),
+    ('mfs_event_elapsed_ms', _i, [_vp, _vp, C.POINTER(C.c_float)]),
+    ('mfs_filter_1d', _i, [C.POINTER(MfsModel1d), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i,
+                           _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    ('mfs_plan_1d_create', _i, [_vpp, C.POINTER(MfsModel1d), _i, _i, _i, _i, _i, _i, _i]),
+    ('mfs_plan_1d_run', _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ('mfs_plan_1d_destroy', _i, [_vp]),
+    ('mfs_plan_1d_geometry', _i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]),
+    ('mfs_quadrature_1d', _i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    ('mfs_comm_unique_id', _i, [_vp]),
+    ('mfs_comm_init', _i, [_vpp, _vp, _i, _i, _i]),
+    ('mfs_allgather_nell', _i, [_vp, _vp, _vp, _u64, _vp]),
+    ('mfs_comm_destroy', _i, [_vp]),
+    ('mfs_memcpy_d2d', _i, [_vp, _vp, _u64, _vp]),
+]
+DECLARED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+
+def lib():
+    """Load libmfs_hip.so once; raise loudly (never fall back) if it is absent or does not load."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfsError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'or `make -C mfs_amd/csrc`. mfs_amd has no CPU fallback.')
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise MfsError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, res, args in _SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != MFS_OK:
+        raise MfsError(f'libmfs_hip error {rc}: {lib().mfs_last_error().decode()}')
+
+
+def ptr(a):
+    """void* of a C-contiguous float64 / int32 NumPy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS']
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().mfs_device_count(C.byref(n)))
+    return n.value
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib().mfs_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+class DeviceBuffer:
+    """Owning handle of a hipMalloc'ed buffer (bench harness / sharded driver keep data resident in HBM)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().mfs_malloc(C.byref(p), self.nbytes))
+        self.ptr = p
+
+    @classmethod
+    def from_array(cls, a, stream=None):
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        if a.nbytes:
+            check(lib().mfs_memcpy_h2d(buf.ptr, ptr(a), a.nbytes, stream))
+        return buf
+
+    def to_array(self, shape, dtype=np.float64, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        if out.nbytes:
+            check(lib().mfs_memcpy_d2h(ptr(out), self.ptr, out.nbytes, stream))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            lib().mfs_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,466 @@
+// capi.hip -- the C ABI of libmfs_hip.so (include/mfs_hip.h): argument checking, device staging, chunked launches,
+// hipGraph capture.  No compute lives here; the kernels are in filter1d_kernel.hpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "filter1d_kernel.hpp"
+
+namespace mfs {
+KernelEntry g_table[MFS_MAX_N + 1][3];  // filled by the static registrars in filter1d_inst.hip
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(MFS_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int check_model(const mfs_model_1d* m, int mode) {
+    if (!m) return fail(MFS_EINVAL, "model is NULL");
+    if (m->trans_kind != MFS_TRANS_OPERATOR && m->trans_kind != MFS_TRANS_GAUSSIAN)
+        return fail(MFS_EINVAL, "unknown trans_kind %d", m->trans_kind);
+    if (m->umap != MFS_U_IDENTITY && m->umap != MFS_U_TANH) return fail(MFS_EINVAL, "unknown umap %d", m->umap);
+    if (m->degree < 0 || m->degree > MFS_MAX_DEGREE)
+        return fail(MFS_EUNSUPPORTED, "polynomial degree %d outside [0, %d]", m->degree, MFS_MAX_DEGREE);
+    if (m->trans_kind == MFS_TRANS_OPERATOR) {
+        if (m->n_terms < 1 || m->n_terms > MFS_MAX_TERMS)
+            return fail(MFS_EUNSUPPORTED, "n_terms %d outside [1, %d]", m->n_terms, MFS_MAX_TERMS);
+        if (m->n_rows != m->n_terms + 1) return fail(MFS_EINVAL, "operator table needs n_rows = n_terms + 1");
+    } else if (m->n_rows != 2) {
+        return fail(MFS_EINVAL, "gaussian table needs n_rows = 2");
+    }
+    if (m->lik_kind < 0 || m->lik_kind > MFS_LIK_GAUSSIAN) return fail(MFS_EINVAL, "unknown lik_kind %d", m->lik_kind);
+    if (m->n_lik < 1 || m->n_lik > MFS_MAX_LIK) return fail(MFS_EINVAL, "n_lik %d outside [1, %d]", m->n_lik, MFS_MAX_LIK);
+    if (!m->coef || !m->lik) return fail(MFS_EINVAL, "model tables are NULL");
+    if (mode < MFS_MODE_RAW || mode > MFS_MODE_SCALED) return fail(MFS_EINVAL, "unknown mode %d", mode);
+    return MFS_OK;
+}
+
+// lanes-per-filter choice: smallest group that holds a row per lane unless overridden (MFS_LANES_PER_FILTER=16|32|64)
+int pick_group(int N) {
+    int want = 0;
+    if (const char* e = getenv("MFS_LANES_PER_FILTER")) want = atoi(e);
+    int gi = (N <= 16) ? 0 : (N <= 32) ? 1 : 2;
+    if (want == 64) gi = 2;
+    else if (want == 32 && N <= 32) gi = 1;
+    else if (want == 16 && N <= 16) gi = 0;
+    return gi;
+}
+
+}  // namespace
+
+struct mfs_plan_1d {
+    mfs_model_1d model;  // device pointers inside
+    int mode, N, T, B, stable, chunk, device;
+    int gi, G, fpb, grid, lds_bytes;
+    double* d_coef = nullptr;
+    double* d_lik = nullptr;
+    double* c_mom = nullptr;
+    double* c_mean = nullptr;
+    double* c_scale = nullptr;
+    double* c_nell = nullptr;
+    int32_t* c_first_nan = nullptr;
+    hipStream_t own_stream = nullptr;
+    // cached graph for the last set of run() pointers
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const void* key[10] = {nullptr};
+    int key_m0_batched = -1;
+};
+
+extern "C" {
+
+int mfs_version(void) { return MFS_ABI_VERSION; }
+const char* mfs_last_error(void) { return g_err.c_str(); }
+
+int mfs_device_count(int* count) {
+    if (!count) return fail(MFS_EINVAL, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return MFS_OK;
+}
+int mfs_set_device(int device) { HIP_TRY(hipSetDevice(device)); return MFS_OK; }
+int mfs_device_synchronize(void) { HIP_TRY(hipDeviceSynchronize()); return MFS_OK; }
+int mfs_device_name(int device, char* buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(MFS_EINVAL, "bad buffer");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return MFS_OK;
+}
+int mfs_malloc(void** dptr, uint64_t bytes) {
+    if (!dptr) return fail(MFS_EINVAL, "dptr is NULL");
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 8);
+    if (e != hipSuccess) return fail(MFS_ENOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return MFS_OK;
+}
+int mfs_free(void* dptr) { if (dptr) HIP_TRY(hipFree(dptr)); return MFS_OK; }
+int mfs_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return MFS_OK;
+}
+int mfs_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return MFS_OK;
+}
+int mfs_memset(void* dst, int value, uint64_t bytes, void* stream) {
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return MFS_OK;
+}
+int mfs_stream_create(void** stream) {
+    if (!stream) return fail(MFS_EINVAL, "stream is NULL");
+    HIP_TRY(hipStreamCreateWithFlags((hipStream_t*)stream, hipStreamNonBlocking));
+    return MFS_OK;
+}
+int mfs_stream_destroy(void* stream) { if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream)); return MFS_OK; }
+int mfs_stream_synchronize(void* stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); return MFS_OK; }
+int mfs_event_create(void** event) {
+    if (!event) return fail(MFS_EINVAL, "event is NULL");
+    HIP_TRY(hipEventCreate((hipEvent_t*)event));
+    return MFS_OK;
+}
+int mfs_event_destroy(void* event) { if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event)); return MFS_OK; }
+int mfs_event_record(void* event, void* stream) { HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return MFS_OK; }
+int mfs_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (!ms) return fail(MFS_EINVAL, "ms is NULL");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return MFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// plans
+// ---------------------------------------------------------------------------------------------------------------
+int mfs_plan_1d_destroy(mfs_plan_1d* p) {
+    if (!p) return MFS_OK;
+    hipSetDevice(p->device);
+    if (p->exec) hipGraphExecDestroy(p->exec);
+    if (p->graph) hipGraphDestroy(p->graph);
+    hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->c_mom); hipFree(p->c_mean); hipFree(p->c_scale);
+    hipFree(p->c_nell); hipFree(p->c_first_nan);
+    if (p->own_stream) hipStreamDestroy(p->own_stream);
+    delete p;
+    return MFS_OK;
+}
+
+int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, int N, int T, int B, int stable,
+                       int chunk, int device) {
+    if (!plan) return fail(MFS_EINVAL, "plan is NULL");
+    *plan = nullptr;
+    if (int rc = check_model(model, mode)) return rc;
+    if (N < 2 || N > MFS_MAX_N) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, %d]", N, MFS_MAX_N);
+    if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
+    if (chunk < 0) return fail(MFS_EINVAL, "negative chunk");
+    const int gi = pick_group(N);
+    const mfs::KernelEntry& ke = mfs::g_table[N][gi];
+    if (!ke.filter) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
+    HIP_TRY(hipSetDevice(device));
+
+    mfs_plan_1d* p = new mfs_plan_1d();
+    p->model = *model;
+    p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device;
+    p->chunk = (chunk == 0 || chunk > T) ? T : chunk;
+    p->gi = gi;
+    p->G = (gi == 0) ? 16 : (gi == 1) ? 32 : 64;
+    p->fpb = ke.waves_per_block * (64 / p->G);
+    p->grid = (B + p->fpb - 1) / p->fpb;
+    p->lds_bytes = p->fpb * ke.lds_doubles_per_filter * 8;
+
+    const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * model->n_rows * (model->degree + 1);
+    const size_t nlik = (size_t)(model->lik_batched ? B : 1) * model->n_lik;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
+    alloc((void**)&p->d_coef, ncoef * 8);
+    alloc((void**)&p->d_lik, nlik * 8);
+    alloc((void**)&p->c_mom, (size_t)B * 2 * N * 8);
+    alloc((void**)&p->c_mean, (size_t)B * 8);
+    alloc((void**)&p->c_scale, (size_t)B * 8);
+    alloc((void**)&p->c_nell, (size_t)B * 8);
+    alloc((void**)&p->c_first_nan, (size_t)B * 4);
+    if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, ncoef * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, nlik * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        mfs_plan_1d_destroy(p);
+        return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "plan setup failed: %s", hipGetErrorString(e));
+    }
+    p->model.coef = p->d_coef;
+    p->model.lik = p->d_lik;
+    *plan = p;
+    return MFS_OK;
+}
+
+int mfs_plan_1d_geometry(const mfs_plan_1d* p, int* lanes_per_filter, int* filters_per_block, int* grid,
+                         int* lds_bytes_per_block) {
+    if (!p) return fail(MFS_EINVAL, "plan is NULL");
+    if (lanes_per_filter) *lanes_per_filter = p->G;
+    if (filters_per_block) *filters_per_block = p->fpb;
+    if (grid) *grid = p->grid;
+    if (lds_bytes_per_block) *lds_bytes_per_block = p->lds_bytes;
+    return MFS_OK;
+}
+
+static int enqueue_chunks(mfs_plan_1d* p, const mfs::Filter1dArgs& base, hipStream_t s) {
+    const mfs::KernelEntry& ke = mfs::g_table[p->N][p->gi];
+    mfs::Filter1dArgs a = base;
+    if (p->T == 0) {  // empty measurement sequence: nell = 0, nothing else to write
+        a.t_begin = 0; a.t_end = 0;
+        hipError_t e = ke.filter(a, p->grid, p->lds_bytes, s);
+        if (e != hipSuccess) return fail(MFS_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+        return MFS_OK;
+    }
+    for (int t0 = 0; t0 < p->T; t0 += p->chunk) {
+        a.t_begin = t0;
+        a.t_end = (t0 + p->chunk < p->T) ? t0 + p->chunk : p->T;
+        hipError_t e = ke.filter(a, p->grid, p->lds_bytes, s);
+        if (e != hipSuccess) return fail(MFS_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
+    }
+    return MFS_OK;
+}
+
+int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const double* d_mean0,
+                    const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
+                    double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream) {
+    if (!p) return fail(MFS_EINVAL, "plan is NULL");
+    if (!d_m0 || !d_out_nell || (p->T > 0 && !d_ys)) return fail(MFS_EINVAL, "m0 / ys / out_nell must not be NULL");
+    if (p->mode != MFS_MODE_RAW && !d_mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
+    if (p->mode == MFS_MODE_SCALED && !d_scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    if (p->B == 0) return MFS_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t s = stream ? (hipStream_t)stream : p->own_stream;
+
+    mfs::Filter1dArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = p->mode; a.T = p->T; a.B = p->B; a.stable = p->stable;
+    a.trans_kind = p->model.trans_kind; a.umap = p->model.umap; a.n_terms = p->model.n_terms;
+    a.degree = p->model.degree; a.n_rows = p->model.n_rows; a.coef_batched = p->model.coef_batched;
+    a.lik_kind = p->model.lik_kind; a.n_lik = p->model.n_lik; a.lik_batched = p->model.lik_batched;
+    a.mean_x_coef = p->model.mean_x_coef; a.coef = p->model.coef; a.lik = p->model.lik;
+    a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
+    a.c_mom = p->c_mom; a.c_mean = p->c_mean; a.c_scale = p->c_scale; a.c_nell = p->c_nell;
+    a.c_first_nan = p->c_first_nan;
+    a.out_mom = d_out_moments; a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
+    a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
+    a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
+
+    const int nchunks = (p->T + p->chunk - 1) / (p->chunk > 0 ? p->chunk : 1);
+    if (nchunks <= 1) return enqueue_chunks(p, a, s);  // one launch: a graph adds only replay overhead
+
+    // several chunk launches: capture them once into a hipGraph keyed on the buffer set, then replay
+    const void* key[10] = {d_m0, d_mean0, d_scale0, d_ys, d_out_moments, d_out_means, d_out_scales, d_out_nell,
+                           d_out_first_nan, nullptr};
+    const bool hit = p->exec && memcmp(key, p->key, sizeof(key)) == 0 && p->key_m0_batched == m0_batched;
+    if (!hit) {
+        if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+        if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+        HIP_TRY(hipStreamBeginCapture(p->own_stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_chunks(p, a, p->own_stream);
+        hipError_t e = hipStreamEndCapture(p->own_stream, &p->graph);
+        if (rc != MFS_OK) return rc;
+        if (e != hipSuccess) return fail(MFS_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        HIP_TRY(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+        memcpy(p->key, key, sizeof(key));
+        p->key_m0_batched = m0_batched;
+    }
+    HIP_TRY(hipGraphLaunch(p->exec, s));
+    return MFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-pointer convenience path
+// ---------------------------------------------------------------------------------------------------------------
+int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B, const double* m0, int m0_batched,
+                  const double* mean0, const double* scale0, const double* ys, int stable, double* out_moments,
+                  double* out_means, double* out_scales, double* out_nell, int32_t* out_first_nan, int device,
+                  void* stream) {
+    if (!m0 || !out_nell || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "m0 / ys / out_nell must not be NULL");
+    if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
+    if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    mfs_plan_1d* p = nullptr;
+    if (int rc = mfs_plan_1d_create(&p, model, mode, N, T, B, stable, 0, device)) return rc;
+    if (B == 0) { mfs_plan_1d_destroy(p); return MFS_OK; }
+    hipStream_t s = stream ? (hipStream_t)stream : p->own_stream;
+    const size_t M2 = 2 * (size_t)N, nb = m0_batched ? B : 1;
+    double *d_m0 = nullptr, *d_mean0 = nullptr, *d_scale0 = nullptr, *d_ys = nullptr, *d_mom = nullptr,
+           *d_means = nullptr, *d_scales = nullptr, *d_nell = nullptr;
+    int32_t* d_fn = nullptr;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
+    auto h2d = [&](void* d, const void* h, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+    };
+    auto d2h = [&](void* h, const void* d, size_t bytes) {
+        if (e == hipSuccess && h && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    };
+    alloc((void**)&d_m0, nb * M2 * 8);
+    alloc((void**)&d_mean0, nb * 8);
+    alloc((void**)&d_scale0, nb * 8);
+    alloc((void**)&d_ys, (size_t)B * T * 8);
+    if (out_moments) alloc((void**)&d_mom, (size_t)B * T * M2 * 8);
+    if (out_means && mode != MFS_MODE_RAW) alloc((void**)&d_means, (size_t)B * T * 8);
+    if (out_scales && mode == MFS_MODE_SCALED) alloc((void**)&d_scales, (size_t)B * T * 8);
+    alloc((void**)&d_nell, (size_t)B * 8);
+    alloc((void**)&d_fn, (size_t)B * 4);
+    h2d(d_m0, m0, nb * M2 * 8);
+    if (mean0) h2d(d_mean0, mean0, nb * 8);
+    if (scale0) h2d(d_scale0, scale0, nb * 8);
+    h2d(d_ys, ys, (size_t)B * T * 8);
+    int rc = MFS_OK;
+    if (e == hipSuccess)
+        rc = mfs_plan_1d_run(p, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn, s);
+    if (rc == MFS_OK) {
+        d2h(out_moments, d_mom, (size_t)B * T * M2 * 8);
+        d2h(out_means, d_means, d_means ? (size_t)B * T * 8 : 0);
+        d2h(out_scales, d_scales, d_scales ? (size_t)B * T * 8 : 0);
+        d2h(out_nell, d_nell, (size_t)B * 8);
+        d2h(out_first_nan, d_fn, (size_t)B * 4);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    hipFree(d_m0); hipFree(d_mean0); hipFree(d_scale0); hipFree(d_ys); hipFree(d_mom); hipFree(d_means);
+    hipFree(d_scales); hipFree(d_nell); hipFree(d_fn);
+    mfs_plan_1d_destroy(p);
+    if (rc != MFS_OK) return rc;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_1d: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const double* scale, int stable,
+                      double* out_weights, double* out_nodes, int device, void* stream) {
+    if (N < 2 || N > MFS_MAX_N) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, %d]", N, MFS_MAX_N);
+    if (B < 0) return fail(MFS_EINVAL, "negative B");
+    if (B == 0) return MFS_OK;
+    if (!ms || !out_weights || !out_nodes) return fail(MFS_EINVAL, "NULL buffer");
+    const int gi = pick_group(N);
+    const mfs::KernelEntry& ke = mfs::g_table[N][gi];
+    if (!ke.quad) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const int G = (gi == 0) ? 16 : (gi == 1) ? 32 : 64;
+    const int fpb = ke.waves_per_block * (64 / G);
+    double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_w = nullptr, *d_x = nullptr;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes); };
+    alloc((void**)&d_ms, (size_t)B * 2 * N * 8);
+    alloc((void**)&d_w, (size_t)B * N * 8);
+    alloc((void**)&d_x, (size_t)B * N * 8);
+    if (mean) alloc((void**)&d_mean, (size_t)B * 8);
+    if (scale) alloc((void**)&d_scale, (size_t)B * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ms, ms, (size_t)B * 2 * N * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && mean) e = hipMemcpyAsync(d_mean, mean, (size_t)B * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)B * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        mfs::Quad1dArgs a{B, stable, d_ms, d_mean, d_scale, d_w, d_x};
+        e = ke.quad(a, (B + fpb - 1) / fpb, fpb * ke.lds_doubles_per_filter * 8, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_weights, d_w, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_nodes, d_x, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_ms); hipFree(d_mean); hipFree(d_scale); hipFree(d_w); hipFree(d_x);
+    if (e != hipSuccess) return fail(MFS_EHIP, "mfs_quadrature_1d: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// RCCL all-gather of the per-replicate NLL vector.  librccl is dlopen'ed on first use so
+// that single-GPU users never pay for loading it.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, mfs_rccl_id, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.handle) return MFS_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(MFS_ERCCL, "cannot dlopen librccl: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, mfs_rccl_id, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+        return fail(MFS_ERCCL, "librccl lacks an expected symbol");
+    g_rccl.handle = h;
+    return MFS_OK;
+}
+#define RCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        int r_ = (expr);                                                                                   \
+        if (r_ != 0) return fail(MFS_ERCCL, "%s failed: %s", #expr,                                        \
+                                 g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error");        \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+int mfs_comm_unique_id(mfs_rccl_id* id) {
+    if (!id) return fail(MFS_EINVAL, "id is NULL");
+    if (int rc = load_rccl()) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id));
+    return MFS_OK;
+}
+
+int mfs_comm_init(void** comm, const mfs_rccl_id* id, int nranks, int rank, int device) {
+    if (!comm || !id) return fail(MFS_EINVAL, "NULL argument");
+    if (rank < 0 || rank >= nranks) return fail(MFS_EINVAL, "rank %d outside [0, %d)", rank, nranks);
+    if (int rc = load_rccl()) return rc;
+    HIP_TRY(hipSetDevice(device));
+    RCCL_TRY(g_rccl.CommInitRank(comm, nranks, *id, rank));
+    return MFS_OK;
+}
+
+int mfs_allgather_nell(void* comm, const double* d_send, double* d_recv, uint64_t count, void* stream) {
+    if (!comm || !d_send || !d_recv) return fail(MFS_EINVAL, "NULL argument");
+    if (int rc = load_rccl()) return rc;
+    RCCL_TRY(g_rccl.AllGather(d_send, d_recv, (size_t)count, 8 /* ncclFloat64 */, comm, (hipStream_t)stream));
+    return MFS_OK;
+}
+
+int mfs_comm_destroy(void* comm) {
+    if (!comm) return MFS_OK;
+    if (int rc = load_rccl()) return rc;
+    RCCL_TRY(g_rccl.CommDestroy(comm));
+    return MFS_OK;
+}
+
+int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MFS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+"""Measurement models (the jax.scipy.stats calls of the reference's models): numeric on arrays, and a device
+`LikelihoodSpec` when traced with the placeholders of `mfs_amd.sym`."""
+import math
+
+import numpy as np
+import scipy.special
+
+from mfs_amd import sym
+
+
+def bernoulli_pmf(y, p):
+    """jax.scipy.stats.bernoulli.pmf(y, p) (mfs/one_dim/ss_models.py:46-47, mfs/multi_dims/ss_models.py:66-67)."""
+    if isinstance(p, sym._Logistic):
+        z = p.z.trimmed()
+        if z.umap not in (None, 'x') or z.degree > 3:
+            raise sym.NotDeviceDescribable('Bernoulli likelihood: logistic of a polynomial in x of degree <= 3')
+        return sym.LikelihoodSpec('bernoulli_logistic', sym._pad(z.coef, 3), component=getattr(p.z, 'component', 0))
+    if sym.is_symbolic(p) or sym.is_symbolic(y):
+        raise sym.NotDeviceDescribable('bernoulli_pmf: p must be 1 / (1 + exp(-poly(x)))')
+    y = np.asarray(y, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    with np.errstate(all='ignore'):
+        return np.exp(scipy.special.xlogy(y, p) + scipy.special.xlog1py(1. - y, -p))
+
+
+def poisson_pmf(y, rate):
+    """jax.scipy.stats.poisson.pmf(y, rate) (mfs/one_dim/ss_models.py:83-84)."""
+    if isinstance(rate, sym._Softplus):
+        q = rate.q.trimmed()
+        if q.umap not in (None, 'x') or q.degree > 1 or np.any(sym._pad(q.coef, 1)[..., 0] != 0.):
+            raise sym.NotDeviceDescribable('Poisson likelihood: rate must be log(1 + exp(l * x))')
+        return sym.LikelihoodSpec('poisson_softplus', sym._pad(q.coef, 1)[..., 1:2])
+    if sym.is_symbolic(rate) or sym.is_symbolic(y):
+        raise sym.NotDeviceDescribable('poisson_pmf: rate must be log(1 + exp(l * x))')
+    y = np.asarray(y, dtype=np.float64)
+    rate = np.asarray(rate, dtype=np.float64)
+    with np.errstate(all='ignore'):
+        return np.exp(scipy.special.xlogy(y, rate) - scipy.special.gammaln(y + 1.) - rate)
+
+
+def norm_pdf(y, loc, scale):
+    """jax.scipy.stats.norm.pdf(y, loc, scale) (dardel/convergence/convergence_mf.py:58-61)."""
+    if isinstance(loc, sym.Poly):
+        q = loc.trimmed()
+        if q.umap not in (None, 'x') or q.degree > 1:
+            raise sym.NotDeviceDescribable('Gaussian likelihood: loc must be l0 * x + l1')
+        c = sym._pad(q.coef, 1)
+        var = np.broadcast_to(np.asarray(scale, dtype=np.float64) ** 2, c.shape[:-1])
+        return sym.LikelihoodSpec('gaussian', np.stack([c[..., 1], c[..., 0], var], axis=-1))
+    if sym.is_symbolic(loc) or sym.is_symbolic(y):
+        raise sym.NotDeviceDescribable('norm_pdf: loc must be l0 * x + l1')
+    with np.errstate(all='ignore'):
+        return np.exp(-0.5 * ((np.asarray(y) - loc) / scale) ** 2) / (math.sqrt(2 * math.pi) * scale)

@@ -226,3 +226,36 @@ def sde_cond_moments_tme_nd(drift: Callable, dispersion: Callable, d: int, dt: f
         return cond_mean(x), np.stack([f(*cols) for f in var_f], axis=-1)
 
     return cond_rms, cond_cms, cond_mean, cond_mean_var
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# operator-form tables by SymPy (for the C port and for cross-checking mfs_amd.tme_poly)
+# ---------------------------------------------------------------------------------------------------------------------
+def operator_tables_1d(drift: Callable, dispersion: Callable, dt: float, tme_order: int, umap: str = 'x'):
+    """Q_1..Q_K (K = 2 tme_order) and the tme.mean_and_cov variance as polynomial coefficient rows in u (u = x or
+    tanh x), derived by applying the generator to an undetermined function f(x) and collecting the coefficients of
+    its derivatives.  Returns an array (K + 1, J + 1): rows Q_1..Q_K then the variance."""
+    x = sp.Symbol('x', real=True)
+    u = sp.Symbol('u', real=True)
+    f = sp.Function('f')(x)
+    a = sp.sympify(drift(x))
+    b = sp.sympify(dispersion(x))
+    gam = sp.Matrix([[b * b]])
+    e = sp.expand(expectation_expr(f, [x], [a], gam, dt, tme_order).doit())
+    K = 2 * tme_order
+    _, cov = mean_and_cov_expr([x], [a], gam, dt, tme_order)
+    rows = []
+    for k in range(1, K + 1):
+        rows.append(e.coeff(sp.Derivative(f, (x, k)) if k > 1 else sp.Derivative(f, x)))
+    rows.append(cov[0, 0])
+    polys = []
+    for r in rows:
+        r = sp.expand(sp.simplify(r)) if umap == 'x' else sp.expand(r.rewrite(sp.tanh))
+        r = r.subs(sp.tanh(x), u) if umap == 'tanh' else r.subs(x, u)
+        polys.append(sp.Poly(sp.expand(r), u))
+    J = max(p.degree() for p in polys)
+    out = np.zeros((K + 1, max(J, 0) + 1))
+    for i, p in enumerate(polys):
+        for (j,), c in p.terms():
+            out[i, j] = float(c)
+    return out
