@@ -52,7 +52,8 @@ def _pad(a, deg):
 
 class Poly:
     """sum_j coef[..., j] u^j with u = x ('x'), u = tanh x ('tanh') or a constant (umap None)."""
-    __array_priority__ = 1000  # make ndarray.__mul__(Poly) defer to Poly.__rmul__
+    __array_priority__ = 1000
+    __array_ufunc__ = None  # ndarray (op) Poly defers to Poly.__r(op)__; np.sin(Poly) etc. raise TypeError
 
     def __init__(self, coef, umap=None):
         self.coef = np.asarray(coef, dtype=np.float64)
