@@ -11,10 +11,11 @@
 #include <string>
 #include <vector>
 
-#include "filter1d_kernel.hpp"
+#include "filter1d_fast.hpp"
 
 namespace mfs {
-KernelEntry g_table[MFS_MAX_N + 1][3];  // filled by the static registrars in filter1d_inst.hip
+KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
+Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
 }
 
 namespace {
@@ -58,15 +59,26 @@ int check_model(const mfs_model_1d* m, int mode) {
     return MFS_OK;
 }
 
-// lanes-per-filter choice: smallest group that holds a row per lane unless overridden (MFS_LANES_PER_FILTER=16|32|64)
-int pick_group(int N) {
+// Kernel choice.  Default: the register-resident fast path with the smallest lane group that holds the N + 1 rows of
+// the extended Hankel matrix.  stable=1 (LDL^T completion breaks the tridiagonal structure) and MFS_SOLVER=dense use
+// the LDS-tile dense path.  MFS_LANES_PER_FILTER=16|32|64 overrides the group width (experiments).
+int pick_slot(int N, int stable) {
+    bool dense = stable != 0;
+    if (const char* e = getenv("MFS_SOLVER")) dense = dense || (strcmp(e, "dense") == 0);
     int want = 0;
     if (const char* e = getenv("MFS_LANES_PER_FILTER")) want = atoi(e);
-    int gi = (N <= 16) ? 0 : (N <= 32) ? 1 : 2;
+    if (dense) {
+        int gi = (N <= 16) ? 0 : (N <= 32) ? 1 : 2;
+        if (want == 64) gi = 2;
+        else if (want == 32 && N <= 32) gi = 1;
+        else if (want == 16 && N <= 16) gi = 0;
+        return gi;
+    }
+    int gi = (N + 1 <= 16) ? 0 : (N + 1 <= 32) ? 1 : 2;
     if (want == 64) gi = 2;
-    else if (want == 32 && N <= 32) gi = 1;
-    else if (want == 16 && N <= 16) gi = 0;
-    return gi;
+    else if (want == 32 && N + 1 <= 32) gi = 1;
+    else if (want == 16 && N + 1 <= 16) gi = 0;
+    return 3 + gi;
 }
 
 }  // namespace
@@ -74,7 +86,7 @@ int pick_group(int N) {
 struct mfs_plan_1d {
     mfs_model_1d model;  // device pointers inside
     int mode, N, T, B, stable, chunk, device;
-    int gi, G, fpb, grid, lds_bytes;
+    int slot, G, fpb, grid, lds_bytes, lds_doubles;
     double* d_coef = nullptr;
     double* d_lik = nullptr;
     double* c_mom = nullptr;
@@ -174,20 +186,22 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     if (N < 2 || N > MFS_MAX_N) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, %d]", N, MFS_MAX_N);
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (chunk < 0) return fail(MFS_EINVAL, "negative chunk");
-    const int gi = pick_group(N);
-    const mfs::KernelEntry& ke = mfs::g_table[N][gi];
-    if (!ke.filter) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
+    const int slot = pick_slot(N, stable & 1);
+    const mfs::KernelEntry& ke = mfs::g_table[N][slot];
+    if (!ke.quad) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
     HIP_TRY(hipSetDevice(device));
 
     mfs_plan_1d* p = new mfs_plan_1d();
     p->model = *model;
     p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device;
     p->chunk = (chunk == 0 || chunk > T) ? T : chunk;
-    p->gi = gi;
-    p->G = (gi == 0) ? 16 : (gi == 1) ? 32 : 64;
+    p->slot = slot;
+    p->G = ke.lanes_per_filter;
     p->fpb = ke.waves_per_block * (64 / p->G);
     p->grid = (B + p->fpb - 1) / p->fpb;
-    p->lds_bytes = p->fpb * ke.lds_doubles_per_filter * 8;
+    p->lds_doubles = ke.lds_doubles_per_filter;
+    if (slot >= 3) p->lds_doubles += (model->n_rows * (model->degree + 1) + 1) & ~1;  // fast path: + model table
+    p->lds_bytes = p->fpb * p->lds_doubles * 8;
 
     const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * model->n_rows * (model->degree + 1);
     const size_t nlik = (size_t)(model->lik_batched ? B : 1) * model->n_lik;
@@ -223,19 +237,23 @@ int mfs_plan_1d_geometry(const mfs_plan_1d* p, int* lanes_per_filter, int* filte
     return MFS_OK;
 }
 
+static hipError_t launch_filter(mfs_plan_1d* p, const mfs::Filter1dArgs& a, hipStream_t s) {
+    if (p->slot >= 3) return mfs::g_fast_filter[p->N][p->slot - 3](a, p->grid, p->lds_doubles, s);
+    return mfs::g_table[p->N][p->slot].filter(a, p->grid, p->lds_bytes, s);
+}
+
 static int enqueue_chunks(mfs_plan_1d* p, const mfs::Filter1dArgs& base, hipStream_t s) {
-    const mfs::KernelEntry& ke = mfs::g_table[p->N][p->gi];
     mfs::Filter1dArgs a = base;
     if (p->T == 0) {  // empty measurement sequence: nell = 0, nothing else to write
         a.t_begin = 0; a.t_end = 0;
-        hipError_t e = ke.filter(a, p->grid, p->lds_bytes, s);
+        hipError_t e = launch_filter(p, a, s);
         if (e != hipSuccess) return fail(MFS_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
         return MFS_OK;
     }
     for (int t0 = 0; t0 < p->T; t0 += p->chunk) {
         a.t_begin = t0;
         a.t_end = (t0 + p->chunk < p->T) ? t0 + p->chunk : p->T;
-        hipError_t e = ke.filter(a, p->grid, p->lds_bytes, s);
+        hipError_t e = launch_filter(p, a, s);
         if (e != hipSuccess) return fail(MFS_EHIP, "kernel launch failed: %s", hipGetErrorString(e));
     }
     return MFS_OK;
@@ -353,13 +371,14 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     if (B < 0) return fail(MFS_EINVAL, "negative B");
     if (B == 0) return MFS_OK;
     if (!ms || !out_weights || !out_nodes) return fail(MFS_EINVAL, "NULL buffer");
-    const int gi = pick_group(N);
-    const mfs::KernelEntry& ke = mfs::g_table[N][gi];
+    const int slot = pick_slot(N, stable & 1);
+    const mfs::KernelEntry& ke = mfs::g_table[N][slot];
     if (!ke.quad) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    const int G = (gi == 0) ? 16 : (gi == 1) ? 32 : 64;
+    const int G = ke.lanes_per_filter;
     const int fpb = ke.waves_per_block * (64 / G);
+    const int quad_lds = fpb * (slot >= 3 ? 2 * N : ke.lds_doubles_per_filter) * 8;
     double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_w = nullptr, *d_x = nullptr;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes); };
@@ -373,7 +392,7 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)B * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         mfs::Quad1dArgs a{B, stable, d_ms, d_mean, d_scale, d_w, d_x};
-        e = ke.quad(a, (B + fpb - 1) / fpb, fpb * ke.lds_doubles_per_filter * 8, s);
+        e = ke.quad(a, (B + fpb - 1) / fpb, quad_lds, s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_weights, d_w, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(out_nodes, d_x, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);

@@ -1,0 +1,392 @@
+// filter1d_fast.hpp -- register-resident 1-D moment-filter step for gfx950 (the default path; the LDS-tile kernel in
+// filter1d_kernel.hpp remains as the "dense" path: stable=True and cross-checks).
+//
+// A filter is owned by G lanes (G = 16: one DPP row; 32; 64), lane l holding row l of the problem in VGPRs.
+//
+// Quadrature (reference mfs/one_dim/quadtures.py:122-133), restructured around two identities of Hankel moment
+// matrices -- same mathematics, O(N^3/6 + N^2) work instead of O(12 N^3):
+//
+//   * H is G shifted by one moment: H = [G[:, 1:], g_N] with g_N = (m_N .. m_{2N-1}).  Since R^-1 G = R^T, the first
+//     triangular solve R^-1 H costs nothing for N-1 of its columns (they are columns of R^T) and the remaining column
+//     R^-1 g_N is exactly row N of the Cholesky factor of the (N+1) x N extended Hankel matrix: lane N carries it
+//     through the same elimination.  (quadtures.py:128, inner triangular_solve)
+//   * K = R^-1 H R^-T is the Jacobi (tridiagonal) matrix of the orthonormal polynomials (Golub & Welsch 1969): with
+//     pivots piv_j = R_jj^2 and sub_j = R_{j+1,j} R_jj,
+//         K_jj = sub_j / piv_j - sub_{j-1} / piv_{j-1},      K_{j+1,j}^2 = piv_{j+1} / piv_j.
+//     The second triangular solve collapses to these ratios.  (quadtures.py:129, outer triangular_solve)
+//   * Golub-Welsch eigensolve (quadtures.py:131-133) on the tridiagonal: lane k isolates eigenvalue k with Sturm
+//     counts and polishes it with safeguarded Newton steps on the characteristic polynomial (all lanes run the same
+//     three-term recurrence on their own abscissa: no cross-lane traffic); the squared first eigenvector components
+//     are w_k = 1 / sum_j c_j p_j(lambda_k)^2 with c_j = piv_0 / piv_j.
+//
+// In exact arithmetic this equals the reference's dense route; in fp64 the two differ by the rounding-level
+// off-tridiagonal noise of the dense K, which is the same size as the difference between any two dense
+// implementations (DESIGN.md "parity"; tests/test_gpu_parity_1d.py compares both paths with the oracle).
+#pragma once
+#include <type_traits>
+
+#include "filter1d_kernel.hpp"
+
+namespace mfs {
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// value of `v` held by lane J of this lane's group
+template <int G, int J>
+__device__ __forceinline__ double bcast(double v) {
+    if constexpr (G == 16) {
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);  // v_mov_b64_dpp row_newbcast:J
+    } else if constexpr (G == 64) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), J);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
+        return __hiloint2double(hi, lo);
+    } else {
+        return __shfl(v, J, G);
+    }
+}
+
+template <int N>
+struct FastTile {
+    static constexpr int M2 = 2 * N;
+    static constexpr int oMom = 0;             // [2N] moment vector (Hankel source)
+    static constexpr int oTab = M2;            // [N][2N + 1] per-node contributions (row padded: conflict-free)
+    static constexpr int TLD = M2 + 1;
+    static constexpr int oLik = oTab + N * TLD;
+    static constexpr int oCoef = (oLik + MFS_MAX_LIK + 1) & ~1;  // model table, n_rows * (degree + 1) doubles
+    static constexpr int fixedDoubles = oCoef;
+};
+
+constexpr int kMaxEigIters = 64;
+
+// Gauss quadrature from the 2N moments in LDS.  Lane l < N returns node x and weight w; other lanes get w = 0.
+// Returns the group-uniform poison flag (a Cholesky pivot was not > 0, as LAPACK potrf / XLA report).
+template <int N, int G>
+__device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const double mean,
+                                                const double scale, double& x_out, double& w_out,
+                                                double* dbg = nullptr) {
+    static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
+    // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
+    const int li = (l <= N) ? l : N;
+    double g[N];
+    static_for<0, N>([&](auto J) { g[J] = mom[li + J]; });
+
+    // -- Cholesky, row per lane, left-looking by column (quadtures.py:127); L[j][k] reaches the other lanes by DPP
+    double Lr[N];
+    double piv[N], sub[N], ipiv[N];  // group-uniform
+    bool poisoned = false;
+    static_for<0, N>([&](auto Jc) {
+        constexpr int j = Jc;
+        double s = g[j];
+        static_for<0, j>([&](auto Kc) {
+            constexpr int k = Kc;
+            s = fma(-Lr[k], bcast<G, j>(Lr[k]), s);
+        });
+        const double pj = bcast<G, j>(s);
+        piv[j] = pj;
+        sub[j] = bcast<G, j + 1>(s);
+        poisoned |= !(pj > 0.0);
+        // 1/sqrt(piv): hardware v_rsq_f64 seed (~1e-8 relative) + one Newton-Raphson step -> ~2e-16
+        const double y0 = __builtin_amdgcn_rsq(pj);
+        const double hh = 0.5 * pj * y0;
+        const double rinv = fma(y0, fma(-hh, y0, 0.5), y0);
+        ipiv[j] = rinv * rinv;
+        Lr[j] = s * rinv;
+    });
+
+    // -- Jacobi matrix: a_j = K_jj, b2_j = K_{j+1,j}^2, and the weight normalisers c_j = piv_0 / piv_j
+    double a[N], b2[N], c[N];
+    double amin = 1.79e308, amax = -1.79e308, bmax2 = 0.0;
+    static_for<0, N>([&](auto Jc) {
+        constexpr int j = Jc;
+        double aj = sub[j] * ipiv[j];
+        if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
+        a[j] = aj;
+        c[j] = piv[0] * ipiv[j];
+        if constexpr (j < N - 1) {
+            b2[j] = piv[j + 1] * ipiv[j];
+            bmax2 = fmax(bmax2, b2[j]);
+        } else {
+            b2[j] = 0.0;
+        }
+        amin = fmin(amin, aj);
+        amax = fmax(amax, aj);
+    });
+
+    if (dbg) {  // diagnostics: the Jacobi matrix this lane's group derived
+        static_for<0, N>([&](auto Jc) { if (l == 0) { dbg[Jc] = a[Jc]; dbg[N + Jc] = b2[Jc]; } });
+    }
+    double lam = 0.0, w = 0.0;
+    if (!poisoned) {
+        // -- eigenvalue k by Sturm counts + Laguerre iteration on the characteristic polynomial p_N (Li & Zeng 1994):
+        //    for a polynomial with only real roots the Laguerre step from x towards the right (left) converges
+        //    monotonically and cubically to the nearest root on that side, from ANY distance.  count(x) = number of
+        //    eigenvalues below x tells the lane which root that is: count == k -> step right lands on lambda_k,
+        //    count == k + 1 -> step left does; otherwise bisect the count bracket [lo, hi).
+        const double rad = 2.0 * sqrt(bmax2);
+        const double width = (amax - amin) + 2.0 * rad;
+        double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
+        const double tol = 1e-15 * fmax(fabs(lo), fabs(hi));  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
+        const int k = (l < N) ? l : N - 1;
+        double x = lo + (hi - lo) * ((double)k + 0.5) * (1.0 / (double)N);
+        bool conv = false;
+        for (int it = 0; it < kMaxEigIters; ++it) {
+            double p0 = 1.0, p1 = a[0] - x, d0 = 0.0, d1 = -1.0, e0 = 0.0, e1 = 0.0;
+            int cnt = (p1 < 0.0) ? 1 : 0;
+            static_for<1, N>([&](auto Jc) {
+                constexpr int j = Jc;
+                const double t = a[j] - x;
+                const double pn = fma(t, p1, -b2[j - 1] * p0);
+                const double dn = fma(t, d1, fma(-b2[j - 1], d0, -p1));
+                const double en = fma(t, e1, fma(-b2[j - 1], e0, -2.0 * d1));
+                cnt += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                p0 = p1; p1 = pn; d0 = d1; d1 = dn; e0 = e1; e1 = en;
+            });
+            if (!conv) {  // a converged lane is frozen
+                if (cnt <= k) lo = x; else hi = x;
+                const double mid = 0.5 * (lo + hi);
+                // S = sqrt((N-1) ((N-1) p'^2 - N p p'')) >= 0 for real-rooted p (clamped against rounding)
+                const double disc = (double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)N * p1 * e1);
+                const double S = copysign(sqrt(fmax(disc, 0.0)), p1);
+                const bool right = (cnt == k), left = (cnt == k + 1);
+                const double den = right ? (d1 - S) : (d1 + S);
+                double xn = x - (double)N * p1 / den;
+                const bool ok = (right && xn >= x && xn < hi) || (left && xn <= x && xn > lo);  // false for NaN
+                if (dbg && l < N) { dbg[2 * N + l] = (double)it; dbg[3 * N + l] = xn - x; dbg[4 * N + l] = tol; dbg[5 * N + l] = (double)cnt; }
+                xn = ok ? xn : mid;
+                conv = (ok && fabs(xn - x) <= tol) || (hi - lo <= tol) || (p1 == 0.0 && (right || left));
+                x = xn;
+            }
+            if (group_or<G>(conv ? 0 : 1) == 0) break;
+        }
+        lam = x;
+        // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2   (quadtures.py:133, V[0, :]**2)
+        double p0 = 1.0, p1 = a[0] - lam, acc = 1.0;
+        static_for<1, N>([&](auto Jc) {
+            constexpr int j = Jc;
+            acc = fma(c[j] * p1, p1, acc);
+            const double pn = fma(a[j] - lam, p1, -b2[j - 1] * p0);
+            p0 = p1; p1 = pn;
+        });
+        w = 1.0 / acc;
+    }
+    const double qnan = __builtin_nan("");
+    x_out = poisoned ? qnan : ((l < N) ? fma(scale, lam, mean) : mean);
+    w_out = poisoned ? qnan : ((l < N) ? w : 0.0);
+    return poisoned;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the filter kernel (fast path)
+// ---------------------------------------------------------------------------------------------------------------
+template <int N, int G, int WPB>
+__global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
+    using L = FastTile<N>;
+    constexpr int M2 = L::M2, TLD = L::TLD;
+    constexpr int FPW = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / G, l = lane - grp * G;
+    const int slot = wave * FPW + grp;
+    const int b = blockIdx.x * (WPB * FPW) + slot;
+    if (b >= a.B) return;  // whole groups leave together; no block-level barrier is ever used
+    double* S = smem + (size_t)slot * lds_doubles;
+    double* mom = S + L::oMom;
+    double* TAB = S + L::oTab;
+    const double* coef = S + L::oCoef;
+    const double* lp = S + L::oLik;
+    const int J1 = a.degree + 1;
+
+    {   // stage the model tables and the carry
+        const double* src = a.coef + (a.coef_batched ? (size_t)b * a.n_rows * J1 : 0);
+        for (int e = l; e < a.n_rows * J1; e += G) S[L::oCoef + e] = src[e];
+        const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
+        for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + e] = (e < a.n_lik) ? ls[e] : 0.0;
+    }
+    double mean = 0.0, scale = 1.0, nell = 0.0;
+    int first_nan = -1;
+    if (a.t_begin == 0) {
+        const double* src = a.m0 + (a.m0_batched ? (size_t)b * M2 : 0);
+        for (int n = l; n < M2; n += G) mom[n] = src[n];
+        if (a.mode != MFS_MODE_RAW) mean = a.mean0[a.m0_batched ? b : 0];
+        if (a.mode == MFS_MODE_SCALED) scale = a.scale0[a.m0_batched ? b : 0];
+    } else {
+        for (int n = l; n < M2; n += G) mom[n] = a.c_mom[(size_t)b * M2 + n];
+        mean = a.c_mean[b];
+        scale = a.c_scale[b];
+        nell = a.c_nell[b];
+        first_nan = a.c_first_nan[b];
+    }
+    wave_sync();
+    const double* yrow = a.ys + (size_t)b * a.T;
+    bool dead = (first_nan >= 0);
+    const double qnan = __builtin_nan("");
+    const bool node = (l < N);
+
+    for (int t = a.t_begin; t < a.t_end; ++t) {
+        const double y = yrow[t];
+        if (!dead) {
+            int bad = 0;
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
+                double x, w;
+                quadrature_fast<N, G>(mom, l, mean, scale, x, w);
+                const double u = (a.umap == MFS_U_TANH) ? tanh(x) : x;
+                double c = 0.0, inv_sc = 1.0, py = 1.0;
+                if (half == 0) {
+                    // ---- prediction (filtering.py:76-79 / 144-148 / 221-225)
+                    double mu, var;
+                    if (a.trans_kind == MFS_TRANS_OPERATOR) {
+                        mu = x + horner(coef, a.degree, u);
+                        var = horner(coef + a.n_terms * J1, a.degree, u);
+                    } else {
+                        mu = a.mean_x_coef * x + horner(coef, a.degree, u);
+                        var = horner(coef + J1, a.degree, u);
+                    }
+                    if (a.mode != MFS_MODE_RAW) {
+                        mean = group_sum<G>(w * mu);
+                        c = mean;
+                        if (a.mode == MFS_MODE_SCALED) {
+                            scale = sqrt(group_sum<G>(w * var));
+                            inv_sc = 1.0 / scale;
+                        }
+                    }
+                    double* row = TAB + (node ? l : 0) * TLD;
+                    if (a.trans_kind == MFS_TRANS_OPERATOR) {
+                        // E[(X'-c)^n | x] = sum_k Q_k(u) D_k(n), D_k(n) = n!/(n-k)! (x-c)^(n-k), advanced in n by
+                        // D_k(n+1) = dx D_k(n) + k D_{k-1}(n)                               (moments.py:141-179)
+                        double Q[MFS_MAX_TERMS + 1], D[MFS_MAX_TERMS + 1];
+                        Q[0] = 1.0; D[0] = 1.0;
+#pragma unroll
+                        for (int k = 1; k <= MFS_MAX_TERMS; ++k) {
+                            Q[k] = (k <= a.n_terms) ? horner(coef + (k - 1) * J1, a.degree, u) : 0.0;
+                            D[k] = 0.0;
+                        }
+                        const double dx = x - c;
+                        double sc_n = w;
+                        for (int n = 0; n < M2; ++n) {
+                            double val = 0.0;
+#pragma unroll
+                            for (int k = MFS_MAX_TERMS; k >= 0; --k) val = fma(Q[k], D[k], val);
+                            if (node) row[n] = sc_n * val;
+                            sc_n *= inv_sc;
+#pragma unroll
+                            for (int k = MFS_MAX_TERMS; k >= 1; --k) D[k] = fma(dx, D[k], (double)k * D[k - 1]);
+                            D[0] *= dx;
+                        }
+                    } else {
+                        // normal closure: E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n-1) v E_{n-2}   (moments.py:70-74)
+                        const double m = mu - c;
+                        double e2 = 1.0, e1 = m, sc_n = w;
+                        if (node) row[0] = sc_n;
+                        sc_n *= inv_sc;
+                        if (node) row[1] = sc_n * m;
+                        for (int n = 2; n < M2; ++n) {
+                            const double e = fma(m, e1, (double)(n - 1) * var * e2);
+                            sc_n *= inv_sc;
+                            if (node) row[n] = sc_n * e;
+                            e2 = e1;
+                            e1 = e;
+                        }
+                    }
+                } else {
+                    // ---- update (filtering.py:82-85 / 151-157 / 228-236)
+                    const double wl = node ? w * likelihood(a.lik_kind, lp, y, x) : 0.0;
+                    py = group_sum<G>(wl);
+                    if (a.mode != MFS_MODE_RAW) {
+                        mean = group_sum<G>(wl * x) / py;
+                        c = mean;
+                    }
+                    if (a.mode == MFS_MODE_SCALED) {
+                        scale = sqrt(group_sum<G>(wl * (x - c) * (x - c)) / py);
+                        inv_sc = 1.0 / scale;
+                    }
+                    const double dx = (x - c) * inv_sc;
+                    double* row = TAB + (node ? l : 0) * TLD;
+                    double p = wl;
+                    for (int n = 0; n < M2; ++n) {
+                        if (node) row[n] = p;
+                        p *= dx;
+                    }
+                    nell -= log(py);
+                }
+                wave_sync();
+                const double ipy = 1.0 / py;
+                for (int n = l; n < M2; n += G) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc += TAB[i * TLD + n];
+                    acc = (half == 0) ? acc : acc * ipy;
+                    mom[n] = acc;
+                    bad |= !finite(acc);
+                }
+                wave_sync();
+            }
+            bad |= (int)(!finite(nell) || !finite(mean) || !finite(scale));
+            bad = group_or<G>(bad);
+            if (bad) { dead = true; first_nan = t; }
+        } else {
+            for (int n = l; n < M2; n += G) mom[n] = qnan;
+            mean = qnan; scale = qnan; nell = qnan;
+            wave_sync();
+        }
+        if (a.out_mom) {
+            double* dst = a.out_mom + ((size_t)b * a.T + t) * M2;
+            for (int n = l; n < M2; n += G) dst[n] = mom[n];
+        }
+        if (l == 0) {
+            if (a.out_mean) a.out_mean[(size_t)b * a.T + t] = mean;
+            if (a.out_scale) a.out_scale[(size_t)b * a.T + t] = scale;
+        }
+    }
+    if (a.t_end >= a.T) {
+        if (l == 0) {
+            a.out_nell[b] = nell;
+            if (a.out_first_nan) a.out_first_nan[b] = first_nan;
+        }
+    } else {
+        for (int n = l; n < M2; n += G) a.c_mom[(size_t)b * M2 + n] = mom[n];
+        if (l == 0) {
+            a.c_mean[b] = mean; a.c_scale[b] = scale; a.c_nell[b] = nell; a.c_first_nan[b] = first_nan;
+        }
+    }
+}
+
+template <int N, int G, int WPB>
+__global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1dArgs a) {
+    constexpr int M2 = 2 * N;
+    constexpr int FPW = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / G, l = lane - grp * G;
+    const int slot = wave * FPW + grp;
+    const int b = blockIdx.x * (WPB * FPW) + slot;
+    if (b >= a.B) return;
+    double* S = smem + (size_t)slot * M2;
+    for (int n = l; n < M2; n += G) S[n] = a.ms[(size_t)b * M2 + n];
+    wave_sync();
+    double x, w;
+    if (a.stable & 2) {  // debug: return (a_j, b2_j) instead of (w, x)
+        __shared__ double dbg[4 * 6 * N];
+        quadrature_fast<N, G>(S, l, 0.0, 1.0, x, w, dbg + slot * 6 * N);
+        wave_sync();
+        if (l < N) {
+            const int sel = a.stable >> 2;  // 0: (a, b2); 1: (iterations, last step); 2: (tol, count)
+            a.out_w[(size_t)b * N + l] = dbg[slot * 6 * N + 2 * sel * N + l];
+            a.out_x[(size_t)b * N + l] = dbg[slot * 6 * N + (2 * sel + 1) * N + l];
+        }
+        return;
+    }
+    quadrature_fast<N, G>(S, l, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w);
+    if (l < N) {
+        a.out_w[(size_t)b * N + l] = w;
+        a.out_x[(size_t)b * N + l] = x;
+    }
+}
+
+}  // namespace mfs

@@ -1,6 +1,6 @@
 // filter1d_inst.hip -- instantiates the 1-D kernels for quadrature orders MFS_NLO..MFS_NHI (one translation unit per
 // range so that `make -j` compiles them in parallel) and registers their launchers.
-#include "filter1d_kernel.hpp"
+#include "filter1d_fast.hpp"
 
 #ifndef MFS_NLO
 #error "compile with -DMFS_NLO=.. -DMFS_NHI=.."
@@ -8,7 +8,8 @@
 
 namespace mfs {
 
-extern KernelEntry g_table[MFS_MAX_N + 1][3];  // [N][0: G=16, 1: G=32, 2: G=64], defined in capi.hip
+extern KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // defined in capi.hip
+extern Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
 
 constexpr int kBlockLdsBudget = 64 * 1024;
 
@@ -53,6 +54,39 @@ void reg(int gi) {
     e.quad = &launch_quad<N, G>;
     e.lds_doubles_per_filter = Tile<N>::kDoubles;
     e.waves_per_block = waves_per_block<N, G>();
+    e.lanes_per_filter = G;
+}
+
+// ---- fast (register-resident) path: single-wave workgroups, LDS = filters per wave x (fixed + model table)
+template <int N, int G>
+hipError_t launch_filter_fast(const Filter1dArgs& a, int grid, int lds_doubles, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter1d_fast_kernel<N, G, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL((filter1d_fast_kernel<N, G, 1>), dim3(grid), dim3(64), (64 / G) * lds_doubles * 8, s, a,
+                       lds_doubles);
+    return hipGetLastError();
+}
+
+template <int N, int G>
+hipError_t launch_quad_fast(const Quad1dArgs& a, int grid, int lds, hipStream_t s) {
+    hipLaunchKernelGGL((quadrature1d_fast_kernel<N, G, 1>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int N, int G>
+void reg_fast(int gi) {
+    KernelEntry& e = g_table[N][3 + gi];
+    g_fast_filter[N][gi] = &launch_filter_fast<N, G>;
+    e.filter = nullptr;
+    e.quad = &launch_quad_fast<N, G>;
+    e.lds_doubles_per_filter = FastTile<N>::fixedDoubles;
+    e.waves_per_block = 1;
+    e.lanes_per_filter = G;
 }
 
 template <int N>
@@ -60,6 +94,9 @@ void reg_all() {
     if constexpr (N <= 16) reg<N, 16>(0);
     if constexpr (N <= 32) reg<N, 32>(1);
     reg<N, 64>(2);
+    if constexpr (N + 1 <= 16) reg_fast<N, 16>(0);
+    if constexpr (N + 1 <= 32) reg_fast<N, 32>(1);
+    reg_fast<N, 64>(2);
 }
 
 template <int LO, int HI>

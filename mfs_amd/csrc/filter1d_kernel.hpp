@@ -582,8 +582,13 @@ using Quad1dLaunch = hipError_t (*)(const Quad1dArgs&, int grid, int lds_bytes, 
 struct KernelEntry {
     Filter1dLaunch filter;
     Quad1dLaunch quad;
-    int lds_doubles_per_filter;
+    int lds_doubles_per_filter;  // dense: complete; fast: fixed part, the model table is added at launch
     int waves_per_block;
+    int lanes_per_filter;
 };
+
+// registry slots per N: [0..2] dense path with G = 16 / 32 / 64, [3..5] fast path with G = 16 / 32 / 64
+constexpr int kSlots = 6;
+using Filter1dFastLaunch = hipError_t (*)(const Filter1dArgs&, int grid, int lds_doubles_per_filter, hipStream_t);
 
 }  // namespace mfs
