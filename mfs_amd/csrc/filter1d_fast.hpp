@@ -51,6 +51,63 @@ __device__ __forceinline__ double bcast(double v) {
     }
 }
 
+// sum over the G lanes of the group, result in every lane.  G = 16 is one DPP row: xor-1, xor-2 inside quads,
+// then half-row mirror and row mirror -- 2 v_mov_b32_dpp + 1 v_add_f64 per stage at VALU latency instead of
+// ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int G>
+__device__ __forceinline__ double gsum(double v) {
+    if constexpr (G == 16) {
+        v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dpp_move<0x141>(v);  // row_half_mirror
+        v += dpp_move<0x140>(v);  // row_mirror
+        return v;
+    } else {
+        return group_sum<G>(v);
+    }
+}
+
+// true when `flag` holds in every lane of this lane's group (all lanes of a group are active together)
+template <int G>
+__device__ __forceinline__ bool gall(bool flag, int grp) {
+    if constexpr (G == 64) {
+        return __builtin_amdgcn_ballot_w64(!flag) == 0ull;
+    } else {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+        const unsigned long long want = ((G == 32) ? 0xffffffffull : 0xffffull) << (grp * G);
+        return (m & want) == want;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ bool gany(bool flag, int grp) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
+    if constexpr (G == 64) return m != 0ull;
+    const unsigned long long want = ((G == 32) ? 0xffffffffull : 0xffffull) << (grp * G);
+    return (m & want) != 0ull;
+}
+
+// acc[r] = row r of the coefficient table evaluated at u, for R rows at once: the Horner recurrences of the rows
+// advance together, so the LDS reads of one degree are in flight together instead of one latency per coefficient.
+template <int R>
+__device__ __forceinline__ void horner_rows(const double* __restrict__ table, const int n_rows, const int degree,
+                                            const double u, double (&acc)[R]) {
+    const int J1 = degree + 1;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = (r < n_rows) ? table[r * J1 + degree] : 0.0;
+    for (int j = degree - 1; j >= 0; --j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = (r < n_rows) ? fma(acc[r], u, table[r * J1 + j]) : 0.0;
+    }
+}
+
 template <int N>
 struct FastTile {
     static constexpr int M2 = 2 * N;
@@ -67,8 +124,8 @@ constexpr int kMaxEigIters = 64;
 // Gauss quadrature from the 2N moments in LDS.  Lane l < N returns node x and weight w; other lanes get w = 0.
 // Returns the group-uniform poison flag (a Cholesky pivot was not > 0, as LAPACK potrf / XLA report).
 template <int N, int G>
-__device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const double mean,
-                                                const double scale, double& x_out, double& w_out,
+__device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const int grp,
+                                                const double mean, const double scale, double& x_out, double& w_out,
                                                 double* dbg = nullptr) {
     static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
     // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
@@ -162,7 +219,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                 conv = (ok && fabs(xn - x) <= tol) || (hi - lo <= tol) || (p1 == 0.0 && (right || left));
                 x = xn;
             }
-            if (group_or<G>(conv ? 0 : 1) == 0) break;
+            if (gall<G>(conv, grp)) break;
         }
         lam = x;
         // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2   (quadtures.py:133, V[0, :]**2)
@@ -235,24 +292,29 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
                 double x, w;
-                quadrature_fast<N, G>(mom, l, mean, scale, x, w);
+                quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w);
                 const double u = (a.umap == MFS_U_TANH) ? tanh(x) : x;
                 double c = 0.0, inv_sc = 1.0, py = 1.0;
                 if (half == 0) {
                     // ---- prediction (filtering.py:76-79 / 144-148 / 221-225)
+                    // every row of the model table at this lane's node, in one pass over the degrees
+                    double rows[MFS_MAX_TERMS + 1];
+                    horner_rows<MFS_MAX_TERMS + 1>(coef, a.n_rows, a.degree, u, rows);
                     double mu, var;
                     if (a.trans_kind == MFS_TRANS_OPERATOR) {
-                        mu = x + horner(coef, a.degree, u);
-                        var = horner(coef + a.n_terms * J1, a.degree, u);
+                        mu = x + rows[0];
+                        var = 0.0;
+#pragma unroll
+                        for (int k = 0; k <= MFS_MAX_TERMS; ++k) var = (k == a.n_terms) ? rows[k] : var;
                     } else {
-                        mu = a.mean_x_coef * x + horner(coef, a.degree, u);
-                        var = horner(coef + J1, a.degree, u);
+                        mu = fma(a.mean_x_coef, x, rows[0]);
+                        var = rows[1];
                     }
                     if (a.mode != MFS_MODE_RAW) {
-                        mean = group_sum<G>(w * mu);
+                        mean = gsum<G>(w * mu);
                         c = mean;
                         if (a.mode == MFS_MODE_SCALED) {
-                            scale = sqrt(group_sum<G>(w * var));
+                            scale = sqrt(gsum<G>(w * var));
                             inv_sc = 1.0 / scale;
                         }
                     }
@@ -264,7 +326,7 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
                         Q[0] = 1.0; D[0] = 1.0;
 #pragma unroll
                         for (int k = 1; k <= MFS_MAX_TERMS; ++k) {
-                            Q[k] = (k <= a.n_terms) ? horner(coef + (k - 1) * J1, a.degree, u) : 0.0;
+                            Q[k] = (k <= a.n_terms) ? rows[k - 1] : 0.0;
                             D[k] = 0.0;
                         }
                         const double dx = x - c;
@@ -297,13 +359,13 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
                 } else {
                     // ---- update (filtering.py:82-85 / 151-157 / 228-236)
                     const double wl = node ? w * likelihood(a.lik_kind, lp, y, x) : 0.0;
-                    py = group_sum<G>(wl);
+                    py = gsum<G>(wl);
                     if (a.mode != MFS_MODE_RAW) {
-                        mean = group_sum<G>(wl * x) / py;
+                        mean = gsum<G>(wl * x) / py;
                         c = mean;
                     }
                     if (a.mode == MFS_MODE_SCALED) {
-                        scale = sqrt(group_sum<G>(wl * (x - c) * (x - c)) / py);
+                        scale = sqrt(gsum<G>(wl * (x - c) * (x - c)) / py);
                         inv_sc = 1.0 / scale;
                     }
                     const double dx = (x - c) * inv_sc;
@@ -328,8 +390,7 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
                 wave_sync();
             }
             bad |= (int)(!finite(nell) || !finite(mean) || !finite(scale));
-            bad = group_or<G>(bad);
-            if (bad) { dead = true; first_nan = t; }
+            if (gany<G>(bad != 0, grp)) { dead = true; first_nan = t; }
         } else {
             for (int n = l; n < M2; n += G) mom[n] = qnan;
             mean = qnan; scale = qnan; nell = qnan;
@@ -373,7 +434,7 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
     double x, w;
     if (a.stable & 2) {  // debug: return (a_j, b2_j) instead of (w, x)
         __shared__ double dbg[4 * 6 * N];
-        quadrature_fast<N, G>(S, l, 0.0, 1.0, x, w, dbg + slot * 6 * N);
+        quadrature_fast<N, G>(S, l, grp, 0.0, 1.0, x, w, dbg + slot * 6 * N);
         wave_sync();
         if (l < N) {
             const int sel = a.stable >> 2;  // 0: (a, b2); 1: (iterations, last step); 2: (tol, count)
@@ -382,7 +443,7 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
         }
         return;
     }
-    quadrature_fast<N, G>(S, l, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w);
+    quadrature_fast<N, G>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w);
     if (l < N) {
         a.out_w[(size_t)b * N + l] = w;
         a.out_x[(size_t)b * N + l] = x;
