@@ -148,10 +148,10 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         piv[j] = pj;
         sub[j] = bcast<G, j + 1>(s);
         poisoned |= !(pj > 0.0);
-        // 1/sqrt(piv): hardware v_rsq_f64 seed (~1e-8 relative) + one Newton-Raphson step -> ~2e-16
+        // 1/sqrt(piv): hardware v_rsq_f64 seed (only ~1e-7 relative) + two Newton-Raphson steps -> ~1e-16
         const double y0 = __builtin_amdgcn_rsq(pj);
-        const double hh = 0.5 * pj * y0;
-        const double rinv = fma(y0, fma(-hh, y0, 0.5), y0);
+        const double y1 = fma(y0, fma(-0.5 * pj * y0, y0, 0.5), y0);
+        const double rinv = fma(y1, fma(-0.5 * pj * y1, y1, 0.5), y1);
         ipiv[j] = rinv * rinv;
         Lr[j] = s * rinv;
     });
