@@ -167,6 +167,42 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
                       double* out_weights, double* out_nodes, int device, void* stream);
 
 /*
+ * ---- N-D moment filter (d = 2), host pointers ------------------------------------------------------------------
+ * Replaces moment_filter_nd_rms / moment_filter_nd_cms (mfs/multi_dims/filtering.py:283-344, 210-280) with the
+ * TME transition of mfs/multi_dims/moments.py:414-479 ('multi-index' signature) for B replicates.  The scaled mode
+ * (:33-207) is not on the device: no reference driver uses it (dardel/prey_predator/mf.py:70 raises for it).
+ *
+ * Model: polynomial drift / dispersion reduced on the host to the operator table Q_kappa(x), 1 <= |kappa| <= 4
+ * (TME order <= 2), dense per-variable extent D: coef [MFS_ND_TERMS][D][D] in graded-lex kappa order
+ * (0,1),(1,0),(0,2),(1,1),(2,0),(0,3),...,(4,0), zeros where the model has no term.  Conditional mean_k = x_k + Q_{e_k}.
+ * The likelihood looks at one state component (mfs/multi_dims/ss_models.py:63-67).
+ *
+ *   N              quadrature order per dimension: s = N(N+1)/2 Gram size, z = N(2N+1) moments (|n| <= 2N-1), 2..7
+ *   multi_indices  [z][2] int32, must equal the graded-lex table (checked: MFS_EINVAL otherwise, mirroring the
+ *                  reference's only raise, multi_dims/filtering.py:238-239)
+ *   inds           [3][s][s] int32 Gram / Hankel gather tables (gram_and_hankel_indices_graded_lexico)
+ *   m0 [z] or [B][z]; mean0 [2] or [B][2] (central mode); ys [B][T]
+ *   out_moments [B][T][z]; out_means [B][T][2] (central; NULL in raw mode); out_nell [B]; out_first_nan [B]
+ */
+#define MFS_ND_TERMS 14
+#define MFS_ND_MAX_EXTENT 6
+typedef struct mfs_model_nd {
+    int32_t d;             /* 2 */
+    int32_t n_terms;       /* MFS_ND_TERMS rows are always passed; terms >= n_terms are known to be zero */
+    int32_t extent;        /* D <= MFS_ND_MAX_EXTENT */
+    int32_t lik_kind;      /* MFS_LIK_* */
+    int32_t n_lik;
+    int32_t lik_component; /* which state component the likelihood reads */
+    const double* coef;    /* [MFS_ND_TERMS][D][D] */
+    const double* lik;     /* [n_lik] */
+} mfs_model_nd;
+
+int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z, const int32_t* multi_indices,
+                  const int32_t* inds, const double* m0, int m0_batched, const double* mean0, const double* ys,
+                  int stable, double* out_moments, double* out_means, double* out_nell, int32_t* out_first_nan,
+                  int device, void* stream);
+
+/*
  * ---- multi-GPU: one process per GPU, replicates sharded, NLL all-gather over RCCL / xGMI -----------------------
  * The reference has no multi-device code (its Monte-Carlo runs are separate OS processes,
  * dardel/run_benes_bernoulli_mf.sh:26-31); replicates share nothing, so the data path needs no collective and the

@@ -26,6 +26,18 @@ class MfsModel1d(C.Structure):
                 ('coef', c_double_p), ('lik', c_double_p)]
 
 
+class MfsModelNd(C.Structure):
+    """struct mfs_model_nd (include/mfs_hip.h)."""
+    _fields_ = [('d', C.c_int32), ('n_terms', C.c_int32), ('extent', C.c_int32), ('lik_kind', C.c_int32),
+                ('n_lik', C.c_int32), ('lik_component', C.c_int32), ('coef', c_double_p), ('lik', c_double_p)]
+
+
+ND_TERMS = 14
+ND_MAX_EXTENT = 6
+# derivative multi-indices kappa, 1 <= |kappa| <= 4, graded-lex (the order of mfs_model_nd.coef rows)
+ND_KAPPAS = [(a, s - a) for s in range(1, 5) for a in range(s + 1)]
+
+
 class MfsError(RuntimeError):
     pass
 
@@ -61,6 +73,8 @@ _SIGNATURES = [
     ('mfs_plan_1d_geometry', _i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
     ('mfs_quadrature_1d', _i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    ('mfs_filter_nd', _i, [C.POINTER(MfsModelNd), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i,
+                           _vp, _vp, _vp, _vp, _i, _vp]),
     ('mfs_comm_unique_id', _i, [_vp]),
     ('mfs_comm_init', _i, [_vpp, _vp, _i, _i, _i]),
     ('mfs_allgather_nell', _i, [_vp, _vp, _vp, _u64, _vp]),

@@ -11,11 +11,14 @@
 #include <string>
 #include <vector>
 
-#include "filter1d_fast.hpp"
+#include "filternd_kernel.hpp"
 
 namespace mfs {
 KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
 Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
+using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
+struct NdEntry { FilterNdLaunch launch; int S, Z, lds_bytes; };
+extern NdEntry g_nd_table[8];  // filternd_inst.hip
 }
 
 namespace {
@@ -483,3 +486,84 @@ int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// N-D filter (d = 2), host pointers
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z,
+                             const int32_t* multi_indices, const int32_t* inds, const double* m0, int m0_batched,
+                             const double* mean0, const double* ys, int stable, double* out_moments,
+                             double* out_means, double* out_nell, int32_t* out_first_nan, int device, void* stream) {
+    if (!model) return fail(MFS_EINVAL, "model is NULL");
+    if (model->d != 2) return fail(MFS_EUNSUPPORTED, "the device N-D path supports d = 2 (got %d)", model->d);
+    if (mode != MFS_MODE_RAW && mode != MFS_MODE_CENTRAL)
+        return fail(MFS_EUNSUPPORTED, "the device N-D path supports raw and central moments");
+    if (N < 2 || N > 7) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, 7] for d = 2", N);
+    const mfs::NdEntry& ke = mfs::g_nd_table[N];
+    if (!ke.launch) return fail(MFS_EUNSUPPORTED, "no N-D kernel compiled for N = %d", N);
+    if (z != ke.Z) return fail(MFS_EINVAL, "The size of multi_indices %d must match that of the moments %d.", z, ke.Z);
+    if (model->extent < 1 || model->extent > MFS_ND_MAX_EXTENT)
+        return fail(MFS_EUNSUPPORTED, "coefficient extent %d outside [1, %d]", model->extent, MFS_ND_MAX_EXTENT);
+    if (model->lik_kind < 0 || model->lik_kind > MFS_LIK_GAUSSIAN || model->n_lik < 1 || model->n_lik > MFS_MAX_LIK ||
+        model->lik_component < 0 || model->lik_component > 1)
+        return fail(MFS_EINVAL, "bad likelihood description");
+    if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
+    if (!multi_indices || !inds || !m0 || !out_nell || !model->coef || !model->lik || (T > 0 && B > 0 && !ys))
+        return fail(MFS_EINVAL, "NULL buffer");
+    if (mode == MFS_MODE_CENTRAL && !mean0) return fail(MFS_EINVAL, "mean0 is required in central mode");
+    // the kernel derives a moment's multi-index from its position: insist on the graded-lex table
+    for (int s = 0, zi = 0; s < 2 * N; ++s)
+        for (int n0 = 0; n0 <= s; ++n0, ++zi)
+            if (multi_indices[2 * zi] != n0 || multi_indices[2 * zi + 1] != s - n0)
+                return fail(MFS_EINVAL, "multi_indices is not the graded-lexicographic table of order 2N-1");
+    if (B == 0) return MFS_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t S = ke.S, Z = ke.Z, nb = m0_batched ? B : 1, DD = (size_t)model->extent * model->extent;
+    double *d_coef = nullptr, *d_lik = nullptr, *d_m0 = nullptr, *d_mean0 = nullptr, *d_ys = nullptr, *d_mom = nullptr,
+           *d_means = nullptr, *d_nell = nullptr;
+    int32_t *d_inds = nullptr, *d_fn = nullptr;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
+    auto h2d = [&](void* d, const void* h, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+    };
+    auto d2h = [&](void* h, const void* d, size_t bytes) {
+        if (e == hipSuccess && h && d && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    };
+    alloc((void**)&d_coef, MFS_ND_TERMS * DD * 8);
+    alloc((void**)&d_lik, model->n_lik * 8);
+    alloc((void**)&d_inds, 3 * S * S * 4);
+    alloc((void**)&d_m0, nb * Z * 8);
+    alloc((void**)&d_mean0, nb * 2 * 8);
+    alloc((void**)&d_ys, (size_t)B * T * 8);
+    if (out_moments) alloc((void**)&d_mom, (size_t)B * T * Z * 8);
+    if (out_means && mode == MFS_MODE_CENTRAL) alloc((void**)&d_means, (size_t)B * T * 2 * 8);
+    alloc((void**)&d_nell, (size_t)B * 8);
+    alloc((void**)&d_fn, (size_t)B * 4);
+    h2d(d_coef, model->coef, MFS_ND_TERMS * DD * 8);
+    h2d(d_lik, model->lik, model->n_lik * 8);
+    h2d(d_inds, inds, 3 * S * S * 4);
+    h2d(d_m0, m0, nb * Z * 8);
+    if (mean0) h2d(d_mean0, mean0, nb * 2 * 8);
+    h2d(d_ys, ys, (size_t)B * T * 8);
+    if (e == hipSuccess) {
+        mfs::FilterNdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = mode; a.T = T; a.B = B; a.stable = stable;
+        a.n_terms_used = model->n_terms; a.D = model->extent;
+        a.lik_kind = model->lik_kind; a.n_lik = model->n_lik; a.lik_component = model->lik_component;
+        a.coef = d_coef; a.lik = d_lik; a.inds = d_inds; a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0;
+        a.ys = d_ys; a.out_mom = d_mom; a.out_mean = d_means; a.out_nell = d_nell; a.out_first_nan = d_fn;
+        e = ke.launch(a, B, s);
+    }
+    d2h(out_moments, d_mom, (size_t)B * T * Z * 8);
+    d2h(out_means, d_means, (size_t)B * T * 2 * 8);
+    d2h(out_nell, d_nell, (size_t)B * 8);
+    d2h(out_first_nan, d_fn, (size_t)B * 4);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_coef); hipFree(d_lik); hipFree(d_inds); hipFree(d_m0); hipFree(d_mean0); hipFree(d_ys); hipFree(d_mom);
+    hipFree(d_means); hipFree(d_nell); hipFree(d_fn);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
+    return MFS_OK;
+}

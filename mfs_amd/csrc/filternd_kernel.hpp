@@ -1,0 +1,461 @@
+// filternd_kernel.hpp -- hand-written HIP for gfx950: the N-D (d = 2) moment-filter time-step loop.
+//
+// Reference: mfs/multi_dims/filtering.py:210-344 (scan bodies :258-277, :326-341, :181-204),
+// mfs/multi_dims/quadratures.py:120-178 (moment_quadrature_nd), mfs/multi_dims/moments.py:414-479 (TME transition).
+//
+// One filter per 256-thread workgroup (4 waves); the k-loop runs inside the kernel.  Per half step:
+//   quadrature_nd  G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; one Cholesky; two pairs
+//                  of triangular solves; both K_k diagonalised TOGETHER by cyclic Jacobi (round-robin tournament,
+//                  2x2 blocks: 2 (s/2)^2 blocks <= 256 threads at s = 21) with the eigenvector matrices accumulated;
+//                  s^2 tensor-product nodes with weights <v0_i, v1_j> v0_i[0] v1_j[0]      (quadratures.py:165-170)
+//   predict        per node, every moment sum_kappa Q_kappa(x) prod_k n_k!/(n_k-kappa_k)! (x_k-c_k)^(n_k-kappa_k),
+//                  fully unrolled over the z moments and the fixed list of |kappa| <= 4 derivative terms, so that all
+//                  power / coefficient indices are compile-time constants (registers, no scratch)
+//   update         likelihood-weighted central / raw / scaled moments
+// and a wave-DPP + LDS tree reduction of the z per-thread accumulators.  No MFMA: s <= 28, fp64, sequential.
+#pragma once
+#include "filter1d_fast.hpp"
+
+namespace mfs {
+
+struct FilterNdArgs {
+    int mode, T, B, stable;
+    int n_terms_used, D;      // coefficient block extent per variable (degree + 1)
+    int lik_kind, n_lik, lik_component;
+    const double* coef;       // [kNdTerms][D][D] in the fixed kappa order below (zeros where the model has no term)
+    const double* lik;        // [n_lik]
+    const int32_t* inds;      // [3][s][s]
+    const double* m0;         // [z] or [B][z]
+    int m0_batched;
+    const double* mean0;      // [2] or [B][2]
+    const double* ys;         // [B][T]
+    double* out_mom;          // [B][T][z]
+    double* out_mean;         // [B][T][2]
+    double* out_nell;
+    int32_t* out_first_nan;
+};
+
+// derivative multi-indices kappa with 1 <= |kappa| <= 4, graded-lex order (the order the host fills `coef` in)
+constexpr int kNdTerms = 14;
+constexpr int kNdMaxD = 6;
+__device__ constexpr int kKap0[kNdTerms] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+__device__ constexpr int kKap1[kNdTerms] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
+
+__device__ __forceinline__ constexpr double ffact(int n, int k) {
+    double r = 1.0;
+    for (int j = 0; j < k; ++j) r *= (double)(n - j);
+    return r;
+}
+
+template <int N>
+struct NdTile {
+    static constexpr int S = N * (N + 1) / 2;        // Gram size
+    static constexpr int Z = N * (2 * N + 1);        // number of moments, |n| <= 2N - 1
+    static constexpr int P = 2 * N;                  // powers 0..2N-1 per coordinate
+    static constexpr int NP = S + (S & 1);
+    static constexpr int HP = NP / 2;
+    static constexpr int LD = NP + 1;
+    static constexpr int R = S * S;                  // tensor-product nodes
+    static constexpr int oMom = 0;
+    static constexpr int oA = (Z + 1) & ~1;          // [NP][LD] G -> R
+    static constexpr int oK = oA + NP * LD;          // [2][NP][LD]
+    static constexpr int oV = oK + 2 * NP * LD;      // [2][NP][LD]
+    static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
+    static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] node weights
+    static constexpr int oLam = oW + ((R + 1) & ~1); // [2][NP]
+    static constexpr int oRed = oLam + 2 * NP;       // [4 waves][Z + 4]
+    static constexpr int oCoef = oRed + 4 * (Z + 4); // [kNdTerms][D][D]
+    static constexpr int oMisc = oCoef + kNdTerms * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
+    static constexpr int kDoubles = oMisc + 8;
+};
+
+__device__ __forceinline__ double wave_sum64(double v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    // every lane of a 16-row now holds its row sum; add the four rows through scalar registers
+    double tot = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * r);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
+        tot += __hiloint2double(hi, lo);
+    }
+    return tot;
+}
+
+__device__ __forceinline__ double poly2d(const double* __restrict__ c, const int D, const double x0, const double x1) {
+    // sum_{a,b} c[a][b] x0^a x1^b, nested Horner
+    double acc = 0.0;
+    for (int a = D - 1; a >= 0; --a) {
+        double row = c[a * D + D - 1];
+        for (int b = D - 2; b >= 0; --b) row = fma(row, x1, c[a * D + b]);
+        acc = fma(acc, x0, row);
+    }
+    return acc;
+}
+
+// pair p of round r in the round-robin tournament on NP players
+template <int NP>
+__device__ __forceinline__ void tournament_pair(const int r, const int P, int& p, int& q) {
+    if (P == 0) { p = NP - 1; q = r; }
+    else { p = r + P; if (p >= NP - 1) p -= NP - 1; q = r - P; if (q < 0) q += NP - 1; }
+}
+
+// Fills lam[2][NP] and W[S][S]; returns block-uniform poison flag.
+template <int N>
+__device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    double* mom = Sm + L::oMom;
+    double* A = Sm + L::oA;
+    double* K = Sm + L::oK;
+    double* V = Sm + L::oV;
+    double* cs = Sm + L::oCs;
+    double* flags = Sm + L::oMisc + 4;
+
+    // -- gather (quadratures.py:151-152); pad rows / columns are zero, V = I
+    for (int e = tid; e < NP * NP; e += nthr) {
+        const int i = e / NP, j = e - i * NP;
+        const bool in = (i < S) && (j < S);
+        A[i * LD + j] = in ? mom[inds[i * S + j]] : 0.0;
+        K[i * LD + j] = in ? mom[inds[S * S + i * S + j]] : 0.0;
+        K[NP * LD + i * LD + j] = in ? mom[inds[2 * S * S + i * S + j]] : 0.0;
+        V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+        V[NP * LD + i * LD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    if (tid == 0) flags[0] = 0.0;
+    __syncthreads();
+
+    // -- Cholesky (quadratures.py:154) or LDL^T completion (mfs/utils.py:495-538)
+    if (!stable) {
+        for (int j = 0; j < S; ++j) {
+            if (tid >= j && tid < S) {
+                double s = A[tid * LD + j];
+                for (int k = 0; k < j; ++k) s -= A[tid * LD + k] * A[j * LD + k];
+                A[tid * LD + j] = s;
+            }
+            __syncthreads();
+            const double d = A[j * LD + j];
+            const double r = sqrt(d), inv = 1.0 / r;
+            __syncthreads();
+            if (tid == 0 && !(d > 0.0)) flags[0] = 1.0;
+            if (tid >= j && tid < S) A[tid * LD + j] = (tid == j) ? r : A[tid * LD + j] * inv;
+            __syncthreads();
+        }
+    } else {
+        double fro = 0.0;
+        for (int e = tid; e < S * S; e += nthr) { const double v = A[(e / S) * LD + (e % S)]; fro += v * v; }
+        fro = wave_sum64(fro);
+        if ((tid & 63) == 0) Sm[L::oRed + (tid >> 6)] = fro;
+        __syncthreads();
+        const double eps = 1e-8 * sqrt(Sm[L::oRed] + Sm[L::oRed + 1] + Sm[L::oRed + 2] + Sm[L::oRed + 3]);
+        __syncthreads();
+        for (int j = 0; j < S; ++j) {
+            if (tid >= j && tid < S) {
+                double s = A[tid * LD + j];
+                for (int k = 0; k < j; ++k) s -= A[tid * LD + k] * (A[j * LD + k] * A[k * LD + k]);
+                A[tid * LD + j] = s;
+            }
+            __syncthreads();
+            const double dj = A[j * LD + j];
+            __syncthreads();
+            if (tid > j && tid < S) A[tid * LD + j] = A[tid * LD + j] / dj;
+            __syncthreads();
+        }
+        for (int j = 0; j < S; ++j) {
+            const double dj = A[j * LD + j];
+            const double fj = (dj < 0.0) ? eps : sqrt(dj);
+            __syncthreads();
+            if (tid >= j && tid < S) A[tid * LD + j] = (tid == j) ? fj : A[tid * LD + j] * fj;
+            __syncthreads();
+        }
+    }
+
+    // -- K_k = R^-1 H_k R^-T (quadratures.py:156-161): columns then rows, both matrices at once
+    if (tid < 2 * S) {
+        double* Kk = K + (tid / S) * NP * LD;
+        const int c = tid % S;
+        for (int i = 0; i < S; ++i) {
+            double s = Kk[i * LD + c];
+            for (int k = 0; k < i; ++k) s -= A[i * LD + k] * Kk[k * LD + c];
+            Kk[i * LD + c] = s / A[i * LD + i];
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * S) {
+        double* Kk = K + (tid / S) * NP * LD;
+        const int i = tid % S;
+        for (int j = 0; j < S; ++j) {
+            double s = Kk[i * LD + j];
+            for (int k = 0; k < j; ++k) s -= Kk[i * LD + k] * A[j * LD + k];
+            Kk[i * LD + j] = s / A[j * LD + j];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * S * S; e += nthr) {
+        double* Kk = K + (e / (S * S)) * NP * LD;
+        const int f = e % (S * S), i = f / S, j = f - i * S;
+        if (i > j) {
+            const double s = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
+            Kk[i * LD + j] = s;
+            Kk[j * LD + i] = s;
+        }
+    }
+    __syncthreads();
+
+    // -- cyclic Jacobi on both matrices with eigenvectors (quadratures.py:163)
+    double prev_off = 1.79e308;
+    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < 2 * S * S; e += nthr) {
+            const double* Kk = K + (e / (S * S)) * NP * LD;
+            const int f = e % (S * S), i = f / S, j = f - i * S;
+            const double v = Kk[i * LD + j];
+            if (i == j) dia += v * v; else off += v * v;
+        }
+        off = wave_sum64(off);
+        dia = wave_sum64(dia);
+        __syncthreads();  // previous readers of the scratch slots are done
+        if ((tid & 63) == 0) { Sm[L::oRed + 2 * (tid >> 6)] = off; Sm[L::oRed + 2 * (tid >> 6) + 1] = dia; }
+        __syncthreads();
+        off = Sm[L::oRed] + Sm[L::oRed + 2] + Sm[L::oRed + 4] + Sm[L::oRed + 6];
+        dia = Sm[L::oRed + 1] + Sm[L::oRed + 3] + Sm[L::oRed + 5] + Sm[L::oRed + 7];
+        if (!finite(off + dia)) { if (tid == 0) flags[0] = 1.0; break; }
+        if (!(off > 1e-31 * dia)) break;
+        if (off < 1e-26 * dia && off > 0.25 * prev_off) break;
+        prev_off = off;
+
+        for (int r = 0; r < NP - 1; ++r) {
+            if (tid < 2 * HP) {
+                const int m = tid / HP, P = tid - m * HP;
+                double* Kk = K + m * NP * LD;
+                int p, q;
+                tournament_pair<NP>(r, P, p, q);
+                const double app = Kk[p * LD + p], aqq = Kk[q * LD + q], apq = Kk[p * LD + q];
+                double c = 1.0, s = 0.0, t = 0.0;
+                if (apq != 0.0) {
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    s = t * c;
+                }
+                cs[(m * HP + P) * 3] = c; cs[(m * HP + P) * 3 + 1] = s; cs[(m * HP + P) * 3 + 2] = t;
+            }
+            __syncthreads();
+            // A <- J^T A J on 2x2 blocks, and V <- V J on row pairs, for both matrices
+            for (int e = tid; e < 2 * HP * HP; e += nthr) {
+                const int m = e / (HP * HP), blk = e - m * HP * HP, P = blk / HP, Q = blk - P * HP;
+                double* Kk = K + m * NP * LD;
+                const double* csm = cs + m * HP * 3;
+                int p1, p2, q1, q2;
+                tournament_pair<NP>(r, P, p1, p2);
+                tournament_pair<NP>(r, Q, q1, q2);
+                const double a11 = Kk[p1 * LD + q1], a12 = Kk[p1 * LD + q2];
+                const double a21 = Kk[p2 * LD + q1], a22 = Kk[p2 * LD + q2];
+                double b11, b12, b21, b22;
+                if (P == Q) {
+                    const double t = csm[3 * P + 2];
+                    b11 = a11 - t * a12; b22 = a22 + t * a12; b12 = 0.0; b21 = 0.0;
+                } else {
+                    const double cP = csm[3 * P], sP = csm[3 * P + 1], cQ = csm[3 * Q], sQ = csm[3 * Q + 1];
+                    const double r11 = cP * a11 - sP * a21, r21 = sP * a11 + cP * a21;
+                    const double r12 = cP * a12 - sP * a22, r22 = sP * a12 + cP * a22;
+                    b11 = cQ * r11 - sQ * r12; b12 = sQ * r11 + cQ * r12;
+                    b21 = cQ * r21 - sQ * r22; b22 = sQ * r21 + cQ * r22;
+                }
+                Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
+                Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
+            }
+            for (int e = tid; e < 2 * S * HP; e += nthr) {
+                const int m = e / (S * HP), f = e - m * S * HP, row = f / HP, P = f - row * HP;
+                double* Vk = V + m * NP * LD;
+                const double* csm = cs + m * HP * 3;
+                int p, q;
+                tournament_pair<NP>(r, P, p, q);
+                const double c = csm[3 * P], s = csm[3 * P + 1];
+                const double vp = Vk[row * LD + p], vq = Vk[row * LD + q];
+                Vk[row * LD + p] = c * vp - s * vq;
+                Vk[row * LD + q] = s * vp + c * vq;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    const bool poisoned = flags[0] != 0.0;
+
+    // -- eigenvalues and tensor-product weights (quadratures.py:165-170)
+    double* lam = Sm + L::oLam;
+    double* W = Sm + L::oW;
+    for (int e = tid; e < 2 * S; e += nthr) lam[(e / S) * NP + (e % S)] = K[(e / S) * NP * LD + (e % S) * (LD + 1)];
+    const double* V0 = V;
+    const double* V1 = V + NP * LD;
+    for (int e = tid; e < S * S; e += nthr) {
+        const int i0 = e / S, i1 = e - i0 * S;
+        double dot = 0.0;
+        for (int row = 0; row < S; ++row) dot = fma(V0[row * LD + i0], V1[row * LD + i1], dot);
+        W[e] = dot * V0[i0] * V1[i1];
+    }
+    __syncthreads();
+    return poisoned;
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R;
+    extern __shared__ __attribute__((aligned(16))) double Sm[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    double* mom = Sm + L::oMom;
+    const double* coef = Sm + L::oCoef;
+    const double* lp = Sm + L::oMisc;
+    const int DD = a.D * a.D;
+
+    for (int e = tid; e < kNdTerms * DD; e += 256) Sm[L::oCoef + e] = a.coef[e];
+    if (tid < 4) Sm[L::oMisc + tid] = (tid < a.n_lik) ? a.lik[tid] : 0.0;
+    {
+        const double* src = a.m0 + (a.m0_batched ? (size_t)b * Z : 0);
+        for (int e = tid; e < Z; e += 256) mom[e] = src[e];
+    }
+    // every thread carries an identical copy of the block-uniform state (mean, nell): they are all computed from the
+    // same LDS-reduced sums, so no broadcast is ever needed
+    double mean0 = 0.0, mean1 = 0.0, nell = 0.0;
+    if (a.mode != MFS_MODE_RAW) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
+    double* red = Sm + L::oRed;
+    if (tid == 0) red[Z] = 0.0;
+    __syncthreads();
+    int first_nan = -1;
+    bool dead = false;
+    const double qnan = __builtin_nan("");
+    const double* yrow = a.ys + (size_t)b * a.T;
+
+    for (int t = 0; t < a.T; ++t) {
+        const double y = yrow[t];
+        if (!dead) {
+            bool bad = false;
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
+                // half 0 = prediction (filtering.py:262-266 / :330-331), half 1 = update (:268-275 / :333-339)
+                const bool poisoned = quadrature_nd<N>(Sm, a.inds, a.stable);
+                const double* lam = Sm + L::oLam;
+                const double* W = Sm + L::oW;
+                const double qm0 = mean0, qm1 = mean1;  // the centre this quadrature's nodes are built around
+                // ---- pass 1: the scalar sums (conditional means, or p_y and the posterior mean)
+                double s0 = 0.0, s1 = 0.0, s4 = 0.0;
+                for (int e = tid; e < R; e += 256) {
+                    const int i0 = e / S, i1 = e - i0 * S;
+                    const double w = W[e];
+                    const double x0 = lam[i0] + qm0, x1 = lam[NP + i1] + qm1;
+                    if (half == 0) {
+                        s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
+                        s1 = fma(w, x1 + poly2d(coef + 0 * DD, a.D, x0, x1), s1);  // kappa = (0, 1)
+                    } else {
+                        const double wl = w * likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
+                        s0 = fma(wl, x0, s0); s1 = fma(wl, x1, s1); s4 += wl;
+                    }
+                }
+                s0 = wave_sum64(s0); s1 = wave_sum64(s1); s4 = wave_sum64(s4);
+                if ((tid & 63) == 0) {
+                    double* r3 = red + (Z + 4) * (tid >> 6);
+                    r3[Z + 1] = s0; r3[Z + 2] = s1; r3[Z + 3] = s4;
+                }
+                __syncthreads();
+                s0 = red[Z + 1] + red[(Z + 4) + Z + 1] + red[2 * (Z + 4) + Z + 1] + red[3 * (Z + 4) + Z + 1];
+                s1 = red[Z + 2] + red[(Z + 4) + Z + 2] + red[2 * (Z + 4) + Z + 2] + red[3 * (Z + 4) + Z + 2];
+                s4 = red[Z + 3] + red[(Z + 4) + Z + 3] + red[2 * (Z + 4) + Z + 3] + red[3 * (Z + 4) + Z + 3];
+                double c0 = 0.0, c1 = 0.0, py = 1.0;
+                if (half == 0) {
+                    if (a.mode != MFS_MODE_RAW) { c0 = s0; c1 = s1; }
+                } else {
+                    py = s4;
+                    if (a.mode != MFS_MODE_RAW) { c0 = s0 / py; c1 = s1 / py; }
+                    nell -= log(py);
+                }
+                // ---- pass 2: per-node contributions to all Z moments about the new centre, in registers
+                double acc[Z];
+#pragma unroll
+                for (int zi = 0; zi < Z; ++zi) acc[zi] = 0.0;
+                for (int e = tid; e < R; e += 256) {
+                    const int i0 = e / S, i1 = e - i0 * S;
+                    double w = W[e];
+                    const double x0 = lam[i0] + qm0, x1 = lam[NP + i1] + qm1;
+                    const double d0 = x0 - c0, d1 = x1 - c1;
+                    double px0[P], px1[P];
+                    px0[0] = 1.0; px1[0] = 1.0;
+#pragma unroll
+                    for (int p = 1; p < P; ++p) { px0[p] = px0[p - 1] * d0; px1[p] = px1[p - 1] * d1; }
+                    if (half == 0) {
+                        double Q[kNdTerms];
+#pragma unroll
+                        for (int k = 0; k < kNdTerms; ++k)
+                            Q[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, x0, x1) : 0.0;
+#pragma unroll
+                        for (int s = 0; s < 2 * N; ++s) {
+#pragma unroll
+                            for (int n0 = 0; n0 <= s; ++n0) {
+                                const int n1 = s - n0, zi = s * (s + 1) / 2 + n0;
+                                double val = px0[n0] * px1[n1];
+#pragma unroll
+                                for (int k = 0; k < kNdTerms; ++k) {
+                                    if (kKap0[k] <= n0 && kKap1[k] <= n1)
+                                        val = fma(Q[k] * (ffact(n0, kKap0[k]) * ffact(n1, kKap1[k])),
+                                                  px0[n0 - kKap0[k]] * px1[n1 - kKap1[k]], val);
+                                }
+                                acc[zi] = fma(w, val, acc[zi]);
+                            }
+                        }
+                    } else {
+                        w *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
+#pragma unroll
+                        for (int s = 0; s < 2 * N; ++s) {
+#pragma unroll
+                            for (int n0 = 0; n0 <= s; ++n0)
+                                acc[s * (s + 1) / 2 + n0] = fma(w, px0[n0] * px1[s - n0], acc[s * (s + 1) / 2 + n0]);
+                        }
+                    }
+                }
+                // ---- block reduction of the Z accumulators: wave DPP sums, then four partials through LDS
+#pragma unroll
+                for (int zi = 0; zi < Z; ++zi) {
+                    const double v = wave_sum64(acc[zi]);
+                    if ((tid & 63) == 0) red[(tid >> 6) * (Z + 4) + zi] = v;
+                }
+                __syncthreads();
+                const double ipy = 1.0 / py;
+                for (int zi = tid; zi < Z; zi += 256) {
+                    double v = red[zi] + red[(Z + 4) + zi] + red[2 * (Z + 4) + zi] + red[3 * (Z + 4) + zi];
+                    v = (half == 0) ? v : v * ipy;
+                    mom[zi] = v;
+                    if (!finite(v)) red[Z] = 1.0;  // slot Z of the first row flags a non-finite moment
+                }
+                if (a.mode != MFS_MODE_RAW) { mean0 = c0; mean1 = c1; }
+                __syncthreads();
+                bad = bad || poisoned || (red[Z] != 0.0);
+                __syncthreads();
+                if (tid == 0) red[Z] = 0.0;
+            }
+            bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1);
+            if (bad) { dead = true; first_nan = t; }
+        } else {
+            for (int zi = tid; zi < Z; zi += 256) mom[zi] = qnan;
+            mean0 = mean1 = nell = qnan;
+        }
+        __syncthreads();
+        if (a.out_mom) {
+            double* dst = a.out_mom + ((size_t)b * a.T + t) * Z;
+            for (int zi = tid; zi < Z; zi += 256) dst[zi] = mom[zi];
+        }
+        if (tid == 0 && a.out_mean) {
+            a.out_mean[((size_t)b * a.T + t) * 2] = mean0;
+            a.out_mean[((size_t)b * a.T + t) * 2 + 1] = mean1;
+        }
+    }
+    if (tid == 0) {
+        a.out_nell[b] = nell;
+        if (a.out_first_nan) a.out_first_nan[b] = first_nan;
+    }
+}
+
+}  // namespace mfs

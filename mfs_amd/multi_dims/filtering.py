@@ -1,0 +1,158 @@
+"""The N-D moment filters on MI355X, mirroring `mfs.multi_dims.filtering`.
+
+Same names, positional order and return tuples as the reference (mfs/multi_dims/filtering.py:283-288, 210-217,
+33-41).  d = 2 runs on `filternd_kernel` (mfs_amd/csrc/filternd_kernel.hpp); d = 1 is routed to the 1-D kernels (the
+reference guarantees the d = 1 N-D path equals the 1-D path, tests/test_filtering.py:304-329).  `ys` may carry a leading
+replicate axis (B, T).  No CPU fallback.
+"""
+import ctypes as C
+from typing import Callable, Tuple
+
+import numpy as np
+
+from mfs_amd import _lib, sym
+from mfs_amd.multi_dims.moments import TransitionRefND
+from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices
+from mfs_amd.tme_poly_nd import TransitionTablesND
+
+__all__ = ['moment_filter_nd_rms', 'moment_filter_nd_cms', 'moment_filter_nd_scms']
+
+
+class _Forbidden:
+    """Stands for a state component the likelihood must not touch while it is traced on another component."""
+
+    def _no(self, *_a, **_k):
+        raise sym.NotDeviceDescribable('the likelihood may depend on one state component only')
+
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __pow__ = __neg__ = _no
+
+
+def _trace_transition(fn_and_flag, mode):
+    fn, signature = fn_and_flag
+    if signature != 'multi-index':
+        raise sym.NotDeviceDescribable("the device N-D path implements the 'multi-index' signature "
+                                       '(sde_cond_moments_tme); the Kan-formula Normal closures use it too upstream '
+                                       'only through index lookups and are not on the device yet')
+    if mode == 'raw':
+        ref = fn(sym.X, sym.ORDER)
+        ok = isinstance(ref, TransitionRefND) and ref.mean is None
+    else:
+        ref = fn(sym.X, sym.ORDER, sym.MEAN)
+        ok = isinstance(ref, TransitionRefND) and ref.mean is sym.MEAN
+    if not isinstance(ref, TransitionRefND):
+        raise sym.NotDeviceDescribable('the transition-moment callable is not device-describable; build it with '
+                                       'mfs_amd.multi_dims.moments.sde_cond_moments_tme')
+    if not ok:
+        raise sym.NotDeviceDescribable('the transition-moment callable does not forward its mean argument')
+    return ref.tables
+
+
+def _trace_likelihood(fn, d):
+    last = None
+    for c in range(d):
+        x = [sym.X if k == c else _Forbidden() for k in range(d)]
+        try:
+            spec = fn(sym.Y, x)
+        except sym.NotDeviceDescribable as e:
+            last = e
+            continue
+        if isinstance(spec, sym.LikelihoodSpec):
+            spec.component = c
+            return spec
+    raise sym.NotDeviceDescribable(f'measurement_cond_pdf is not device-describable: {last}')
+
+
+def _model_struct(tables: TransitionTablesND, lik: sym.LikelihoodSpec):
+    if tables.d != 2:
+        raise sym.NotDeviceDescribable('the device N-D path supports d = 2')
+    dense, D = tables.dense_table()
+    if D > _lib.ND_MAX_EXTENT:
+        raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds MFS_ND_MAX_EXTENT = {_lib.ND_MAX_EXTENT}')
+    coef = np.zeros((_lib.ND_TERMS, D, D))
+    last = 0
+    for t, kap in enumerate(tables.kappas):
+        kap = tuple(int(v) for v in kap)
+        if kap not in _lib.ND_KAPPAS:
+            raise sym.NotDeviceDescribable(f'derivative term {kap} needs |kappa| <= 4, i.e. tme_order <= 2 on the device')
+        row = _lib.ND_KAPPAS.index(kap)
+        coef[row] = dense[t]
+        last = max(last, row + 1)
+    lp = np.ascontiguousarray(lik.params, dtype=np.float64)
+    if lp.ndim != 1:
+        raise sym.NotDeviceDescribable('per-replicate likelihood parameters are not supported on the N-D path yet')
+    m = _lib.MfsModelNd()
+    m.d, m.n_terms, m.extent = 2, last, D
+    m.lik_kind, m.n_lik, m.lik_component = _lib.LIK[lik.kind], lp.shape[0], lik.component
+    m.coef = coef.ctypes.data_as(_lib.c_double_p)
+    m.lik = lp.ctypes.data_as(_lib.c_double_p)
+    return m, (coef, lp)
+
+
+def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, device):
+    multi_indices, inds = moments_partial_order
+    multi_indices = np.asarray(multi_indices)
+    ms0 = np.ascontiguousarray(ms0, dtype=np.float64)
+    if multi_indices.shape[0] != ms0.shape[-1]:  # the reference's only raise (mfs/multi_dims/filtering.py:238-239)
+        raise ValueError(f'The size of multi_indices {multi_indices.shape[0]} must match that of cms0 {ms0.shape[-1]}.')
+    d = multi_indices.shape[-1]
+    inds = np.asarray(inds)
+    s = inds.shape[1]
+    N = next((n for n in range(2, 8) if n * (n + 1) // 2 == s), None)
+    if d != 2 or N is None:
+        raise sym.NotDeviceDescribable(f'the device N-D path supports d = 2 with 2 <= N <= 7 (got d = {d}, s = {s})')
+    ys = np.asarray(ys, dtype=np.float64)
+    squeeze = ys.ndim == 1
+    ys2 = np.ascontiguousarray(ys[None, :] if squeeze else ys)
+    B, T = ys2.shape
+    batched = ms0.ndim == 2
+    if batched and ms0.shape[0] != B:
+        raise ValueError(f'initial moments batch {ms0.shape[0]} does not match ys batch {B}')
+    z = multi_indices.shape[0]
+    mean_a = None
+    if mode == 'central':
+        mean_a = np.ascontiguousarray(np.broadcast_to(np.asarray(mean0, dtype=np.float64), ((B, 2) if batched else (2,))))
+    model, keep = _model_struct(tables, lik)
+    mi32 = np.ascontiguousarray(multi_indices, dtype=np.int32)
+    inds32 = np.ascontiguousarray(inds, dtype=np.int32)
+    out_m = np.empty((B, T, z))
+    out_mean = np.empty((B, T, 2)) if mode == 'central' else None
+    out_nell, out_fn = np.empty((B,)), np.empty((B,), dtype=np.int32)
+    _lib.check(_lib.lib().mfs_filter_nd(C.byref(model), _lib.MODE[mode], N, T, B, z, _lib.ptr(mi32), _lib.ptr(inds32),
+                                        _lib.ptr(ms0), int(batched), _lib.ptr(mean_a), _lib.ptr(ys2),
+                                        int(bool(stable)), _lib.ptr(out_m), _lib.ptr(out_mean), _lib.ptr(out_nell),
+                                        _lib.ptr(out_fn), device, None))
+    del keep
+    if squeeze:
+        out_m, out_nell, out_fn = out_m[0], out_nell[0], out_fn[0]
+        out_mean = None if out_mean is None else out_mean[0]
+    return out_m, out_mean, out_nell, out_fn
+
+
+def moment_filter_nd_rms(state_cond_raw_moments: Tuple[Callable, str], measurement_cond_pdf: Callable, ys,
+                         moments_partial_order, rms0, stable: bool = False, *, device: int = 0,
+                         return_first_nan: bool = False):
+    """Filtering with raw moments (mfs/multi_dims/filtering.py:283-344): returns (rmss (T, z), nell)."""
+    tables = _trace_transition(state_cond_raw_moments, 'raw')
+    lik = _trace_likelihood(measurement_cond_pdf, tables.d)
+    m, _, nell, fn = _run_nd('raw', tables, lik, ys, moments_partial_order, rms0, None, stable, device)
+    return (m, nell, fn) if return_first_nan else (m, nell)
+
+
+def moment_filter_nd_cms(state_cond_central_moments: Tuple[Callable, str], state_cond_mean: Callable,
+                         measurement_cond_pdf: Callable, ys, moments_partial_order, cms0, mean0,
+                         stable: bool = False, *, device: int = 0, return_first_nan: bool = False):
+    """Filtering with central moments (mfs/multi_dims/filtering.py:210-280): returns (cmss, means (T, d), nell)."""
+    tables = _trace_transition(state_cond_central_moments, 'central')
+    ref = state_cond_mean(sym.X)
+    if not (isinstance(ref, TransitionRefND) and ref.tables is tables):
+        raise sym.NotDeviceDescribable('state_cond_mean must come from the same sde_cond_moments_tme call as the '
+                                       'conditional central moments')
+    lik = _trace_likelihood(measurement_cond_pdf, tables.d)
+    m, means, nell, fn = _run_nd('central', tables, lik, ys, moments_partial_order, cms0, mean0, stable, device)
+    return (m, means, nell, fn) if return_first_nan else (m, means, nell)
+
+
+def moment_filter_nd_scms(*args, **kwargs):
+    """Scaled-central N-D filter (mfs/multi_dims/filtering.py:33-207).  Not on the device: no reference driver uses
+    it (dardel/prey_predator/mf.py:70 raises NotImplementedError for it) -- raises rather than falling back."""
+    raise sym.NotDeviceDescribable('moment_filter_nd_scms is not implemented on the device (raw and central are)')

@@ -40,3 +40,33 @@ class GaussianSum1D(NamedTuple):
         scms = cms / np.sqrt(variance) ** np.arange(2 * N)
         return cls(means=means, variances=variances, weights=weights, mean=centre, variance=variance,
                    rms=rms, cms=cms, scms=scms)
+
+
+class GaussianSumND(NamedTuple):
+    """Multidimensional Gaussian-sum distribution (mfs/utils.py:77-125)."""
+    d: int
+    means: np.ndarray
+    covs: np.ndarray
+    weights: np.ndarray
+    mean: np.ndarray
+    cov: np.ndarray
+    rms: np.ndarray
+    cms: np.ndarray
+
+    def sampler(self, rng: np.random.Generator, nsamples: int):
+        cs = rng.choice(self.means.shape[0], size=nsamples, p=self.weights)
+        chol = np.linalg.cholesky(self.covs[cs])
+        return self.means[cs] + np.einsum('...ij,...j->...i', chol, rng.standard_normal((nsamples, self.d)))
+
+    @classmethod
+    def new(cls, means, covs, weights, multi_indices):
+        from mfs_amd.multi_dims.moments import raw_moments_mvn_kan
+        means, covs, weights = (np.asarray(a, dtype=np.float64) for a in (means, covs, weights))
+        d = means.shape[1]
+        centre = np.sum(means * weights[:, None], axis=0)
+        cov = sum(w * (c + np.outer(m, m)) for m, c, w in zip(means, covs, weights)) - np.outer(centre, centre)
+        rms = sum(w * np.array([raw_moments_mvn_kan(m, c, mi) for mi in multi_indices])
+                  for m, c, w in zip(means, covs, weights))
+        cms = sum(w * np.array([raw_moments_mvn_kan(m - centre, c, mi) for mi in multi_indices])
+                  for m, c, w in zip(means, covs, weights))
+        return cls(d=d, means=means, covs=covs, weights=weights, mean=centre, cov=cov, rms=rms, cms=cms)

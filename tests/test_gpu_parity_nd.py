@@ -1,0 +1,91 @@
+"""GPU parity of the N-D (d = 2) path against the oracle (BASELINE config 5 in miniature).
+
+Individual nodes / weights of the N-D rule are not unique when the K_k have repeated eigenvalues (SURVEY section 7,
+hard part 4), so only filter outputs -- moments, means, NLL -- are compared."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from mfs_amd import synth, sym
+from mfs_amd.multi_dims import filtering, moments, ss_models
+from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, gram_and_hankel_indices_graded_lexico
+from oracle import multi_dims as omd, tme_sympy
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_moments(got, ref, mi, rtol):
+    """Relative error per moment with the natural magnitude prod_k sigma_k^{n_k} as the floor of the denominator:
+    first-order central moments and odd moments of near-symmetric laws are rounding noise around zero."""
+    got, ref, mi = np.asarray(got), np.asarray(ref), np.asarray(mi)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    d = mi.shape[1]
+    second = [int(np.where((mi == 2 * np.eye(d, dtype=int)[k]).all(axis=1))[0][0]) for k in range(d)]
+    m2 = np.stack([np.abs(ref[:, second[k]]) for k in range(d)], axis=-1)          # (T, d): E[(x_k - c_k)^2] or E[x_k^2]
+    natural = np.prod(np.sqrt(m2)[:, None, :] ** mi[None, :, :], axis=-1)          # (T, z)
+    scale = np.maximum(np.abs(ref), natural * 1e-2 + 1e-300)
+    err = np.abs(got - ref) / scale
+    assert np.nanmax(err) <= rtol, f'max scaled error {np.nanmax(err):.3e} > {rtol}'
+
+
+def _setup(N, tme_order=2):
+    d = 2
+    mi = generate_graded_lexico_multi_indices(d, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, d)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    fns = moments.sde_cond_moments_tme(drift, disp, dt, tme_order)
+    _, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    ofns = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, tme_order, mi)
+    return mi, inds, dt, gs, fns, pmf, ogs, ofns, opmf
+
+
+@pytest.mark.parametrize('N,T,tme_order', [(2, 80, 2), (3, 60, 2), (4, 40, 1), (6, 12, 2)])
+def test_prey_predator_central_and_raw(N, T, tme_order):
+    mi, inds, dt, gs, fns, pmf, ogs, ofns, opmf = _setup(N, tme_order)
+    B = 3
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=N)
+    cmss, means, nell = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms,
+                                                       gs.mean)
+    rmss, nell_r = filtering.moment_filter_nd_rms((fns[0], 'multi-index'), pmf, ys, (mi, inds), gs.rms)
+    assert cmss.shape == (B, T, mi.shape[0]) and means.shape == (B, T, 2) and nell.shape == (B,)
+    for b in range(B if N < 6 else 1):
+        rc = omd.moment_filter_nd_cms((ofns[1], 'multi-index'), ofns[2], opmf, ys[b], (mi, inds), ogs.cms, ogs.mean)
+        npt.assert_allclose(nell[b], rc[2], rtol=1e-6)
+        npt.assert_allclose(means[b], rc[1], rtol=1e-6)
+        _assert_moments(cmss[b], rc[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
+        if N <= 4:
+            rr = omd.moment_filter_nd_rms((ofns[0], 'multi-index'), opmf, ys[b], (mi, inds), ogs.rms)
+            npt.assert_allclose(nell_r[b], rr[1], rtol=1e-6)
+            npt.assert_allclose(rmss[b], rr[0], rtol=1e-6)
+    # raw and central filters agree with each other on the device (reference tests/test_filtering.py:229-242)
+    # (raw monomial Gram matrices around (1, 1) with variance 1e-3 are numerically singular at N = 6: raw mode
+    #  NaN-poisons there in any fp64 implementation, so the cross-check stops at N = 4)
+    if N <= 4:
+        npt.assert_allclose(means[:, :, 0], rmss[:, :, 2], rtol=1e-6)
+        npt.assert_allclose(means[:, :, 1], rmss[:, :, 1], rtol=1e-6)
+    else:
+        assert np.all(np.isfinite(nell))
+
+
+def test_nd_shapes_errors_and_single_trajectory():
+    mi, inds, dt, gs, fns, pmf, *_ = _setup(3)
+    ys, _ = synth.prey_predator_batch(2, 20, dt, seed=1)
+    m1, means1, nell1 = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys[1], (mi, inds), gs.cms,
+                                                       gs.mean)
+    mB, meansB, nellB = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms,
+                                                       gs.mean)
+    npt.assert_array_equal(m1, mB[1])
+    assert np.ndim(nell1) == 0 and nell1 == nellB[1]
+    with pytest.raises(ValueError, match='must match'):  # the reference's only raise, multi_dims/filtering.py:238
+        filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms[:-1], gs.mean)
+    with pytest.raises(sym.NotDeviceDescribable):
+        filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
+    with pytest.raises(sym.NotDeviceDescribable):
+        filtering.moment_filter_nd_scms()
+    # NaN poisoning is per replicate
+    cms0 = np.tile(gs.cms, (2, 1))
+    cms0[0, 5] = -1.  # E[(x0 - m0)^2] < 0
+    m, means, nell, fn = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), cms0,
+                                                        np.tile(gs.mean, (2, 1)), return_first_nan=True)
+    assert fn[0] == 0 and np.isnan(nell[0]) and np.all(np.isnan(m[0]))
+    assert fn[1] == -1 and nell[1] == nellB[1]
