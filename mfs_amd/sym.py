@@ -89,7 +89,10 @@ class Poly:
             return v
         if isinstance(v, _Placeholder) or isinstance(v, _Expr):
             raise NotDeviceDescribable(f'{v!r} cannot be used in a polynomial expression')
-        return Poly(_as_coef(v))
+        try:
+            return Poly(_as_coef(v))
+        except (TypeError, ValueError) as e:
+            raise NotDeviceDescribable(f'{type(v).__name__} cannot be used in a polynomial expression') from e
 
     # -- ring operations
     def __add__(self, o):

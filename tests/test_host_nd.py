@@ -1,0 +1,87 @@
+"""CPU-only checks of the N-D host side: multi-index tables against the golden tables generated from the reference,
+the N-D polynomial-ring TME generator against the oracle's SymPy differentiation, Kan moments, model tracing."""
+import os
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from mfs_amd import _lib, sym, tme_poly_nd
+from mfs_amd.multi_dims import filtering, moments, multi_indices as mid, ss_models
+from mfs_amd.utils import GaussianSumND
+from oracle import multi_dims as omd, tme_sympy
+
+
+@pytest.mark.parametrize('N,d', [(3, 1), (3, 2), (4, 2), (5, 2), (6, 2), (2, 3), (3, 3)])
+def test_multi_index_tables_match_reference_golden(golden_dir, N, d):
+    g = np.load(os.path.join(golden_dir, 'multi_indices.npz'))
+    npt.assert_array_equal(mid.generate_graded_lexico_multi_indices(d, 2 * N - 1, 0), g[f'mi_N{N}_d{d}'])
+    npt.assert_array_equal(mid.gram_and_hankel_indices_graded_lexico(N, d), g[f'inds_N{N}_d{d}'])
+
+
+def test_multi_index_probes_match_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'multi_indices.npz'))
+    npt.assert_array_equal([mid.graded_lexico_indexof_multi_index(list(p)) for p in g['probe_mi']], g['probe_index'])
+    npt.assert_array_equal([mid.graded_lexico_indexof_multi_index(list(p), lower_sum=2) for p in g['probe_mi'][1:]],
+                           g['probe_index_lower2'])
+    npt.assert_array_equal([mid.sizeof_multi_indices(*a) for a in g['size_args']], g['size_vals'])
+    npt.assert_array_equal(mid.generate_graded_lexico_multi_indices(3, 4, 2), g['mi_lower_d3'])
+    npt.assert_array_equal(mid.find_indices(g['mi_N4_d2']), np.arange(g['mi_N4_d2'].shape[0]))
+
+
+@pytest.mark.parametrize('order', [1, 2])
+def test_nd_tme_tables_match_sympy_on_prey_predator(order):
+    mi = mid.generate_graded_lexico_multi_indices(2, 5)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    r, c, s, mu, mv = moments.sde_cond_moments_tme(drift, disp, dt, order)
+    _, _, ogs, odrift, odisp, _, _ = omd.prey_predator(mi)
+    orms, ocms, omean, omv = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, order, mi)
+    x = np.array([[1.0, 1.1], [0.9, 1.2], [1.3, 0.7], [0.5, 1.6]])
+    npt.assert_allclose(c(x, mi, np.array([1.01, 0.98])), ocms(x, mi, np.array([1.01, 0.98])), rtol=1e-12, atol=1e-18)
+    npt.assert_allclose(r(x, mi), orms(x, mi), rtol=1e-12)
+    npt.assert_allclose(mu(x), omean(x), rtol=1e-14)
+    npt.assert_allclose(mv(x)[1], omv(x)[1], rtol=1e-12, atol=1e-20)
+    npt.assert_allclose(gs.rms, ogs.rms, rtol=1e-13)
+    npt.assert_allclose(gs.cms, ogs.cms, rtol=1e-12, atol=1e-20)
+
+
+def test_nd_tracing_and_model_struct():
+    mi = mid.generate_graded_lexico_multi_indices(2, 5)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    r, c, s, mu, mv = moments.sde_cond_moments_tme(drift, disp, dt, 2)
+    tables = filtering._trace_transition((c, 'multi-index'), 'central')
+    lik = filtering._trace_likelihood(pmf, 2)
+    assert lik.kind == 'bernoulli_logistic' and lik.component == 0
+    npt.assert_allclose(lik.params, [-1., 0., 0., 1.])  # 1 / (1 + exp(-x^3 + 1))
+    m, keep = filtering._model_struct(tables, lik)
+    assert (m.d, m.extent, m.lik_component) == (2, 5, 0) and m.n_terms <= _lib.ND_TERMS
+    coef = keep[0]
+    # row order is the fixed graded-lex kappa list the kernel unrolls over
+    for t, kap in enumerate(tables.kappas):
+        row = _lib.ND_KAPPAS.index(tuple(int(v) for v in kap))
+        npt.assert_array_equal(coef[row][:tables.Q[t].coef.shape[0], :tables.Q[t].coef.shape[1]], tables.Q[t].coef)
+    with pytest.raises(sym.NotDeviceDescribable):  # likelihood on both components
+        filtering._trace_likelihood(lambda y, x: pmf(y, [x[0] + x[1], x[1]]), 2)
+    with pytest.raises(sym.NotDeviceDescribable):  # tme_3 needs |kappa| up to 6
+        r3, c3, *_ = moments.sde_cond_moments_tme(drift, disp, dt, 3)
+        filtering._model_struct(filtering._trace_transition((c3, 'multi-index'), 'central'), lik)
+    with pytest.raises(sym.NotDeviceDescribable):
+        moments.sde_cond_moments_tme(lambda x: np.array([x[0] / x[1], x[1]], dtype=object), disp, dt, 2)
+
+
+def test_kan_and_extractors():
+    mean, cov = np.array([0.3, -0.2]), np.array([[0.5, 0.1], [0.1, 0.3]])
+    for n in ([0, 0], [1, 0], [1, 1], [2, 0], [2, 2], [3, 1], [0, 5]):
+        npt.assert_allclose(moments.raw_moments_mvn_kan(mean, cov, n), omd.raw_moments_mvn_kan(mean, cov, n), rtol=1e-13)
+    npt.assert_allclose(moments.central_moments_mvn_kan(cov, [2, 2]), cov[0, 0] * cov[1, 1] + 2 * cov[0, 1] ** 2)
+    assert moments.central_moments_mvn_kan(cov, [2, 1]) == 0.
+    mi = mid.generate_graded_lexico_multi_indices(2, 3)
+    rms = np.array([moments.raw_moments_mvn_kan(mean, cov, m) for m in mi])
+    npt.assert_allclose(moments.extract_mean(rms, 2), mean)
+    npt.assert_allclose(moments.extract_cov(rms, 2), cov + np.outer(mean, mean))
+    npt.assert_allclose(moments.marginalise_moments(rms, 2, 2, 0),
+                        [moments.raw_moments_mvn_kan(mean, cov, [p, 0]) for p in range(4)])
+    gs = GaussianSumND.new(np.array([[1., 1.], [1., 1.]]), np.array([np.eye(2), 2 * np.eye(2)]) * 1e-3,
+                           np.array([0.5, 0.5]), mi)
+    npt.assert_allclose(gs.mean, [1., 1.])
+    npt.assert_allclose(gs.cov, 1.5e-3 * np.eye(2))
