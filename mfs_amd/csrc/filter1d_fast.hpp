@@ -68,7 +68,7 @@ __device__ __forceinline__ double gsum(double v) {
         v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
         v += dpp_move<0x141>(v);  // row_half_mirror
         v += dpp_move<0x140>(v);  // row_mirror
-        return v;
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150, 0xf, 0xf, false);  // lane 0's sum to every lane
     } else {
         return group_sum<G>(v);
     }

