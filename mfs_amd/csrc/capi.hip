@@ -97,6 +97,7 @@ struct mfs_plan_1d {
     double* c_scale = nullptr;
     double* c_nell = nullptr;
     int32_t* c_first_nan = nullptr;
+    double* c_lam = nullptr;
     hipStream_t own_stream = nullptr;
     // cached graph for the last set of run() pointers
     hipGraph_t graph = nullptr;
@@ -175,7 +176,7 @@ int mfs_plan_1d_destroy(mfs_plan_1d* p) {
     if (p->exec) hipGraphExecDestroy(p->exec);
     if (p->graph) hipGraphDestroy(p->graph);
     hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->c_mom); hipFree(p->c_mean); hipFree(p->c_scale);
-    hipFree(p->c_nell); hipFree(p->c_first_nan);
+    hipFree(p->c_nell); hipFree(p->c_first_nan); hipFree(p->c_lam);
     if (p->own_stream) hipStreamDestroy(p->own_stream);
     delete p;
     return MFS_OK;
@@ -217,6 +218,7 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     alloc((void**)&p->c_scale, (size_t)B * 8);
     alloc((void**)&p->c_nell, (size_t)B * 8);
     alloc((void**)&p->c_first_nan, (size_t)B * 4);
+    if (p->chunk < T && slot >= 3) alloc((void**)&p->c_lam, (size_t)B * 2 * p->G * 8);
     if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, ncoef * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, nlik * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
@@ -283,6 +285,7 @@ int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const do
     a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
     a.c_mom = p->c_mom; a.c_mean = p->c_mean; a.c_scale = p->c_scale; a.c_nell = p->c_nell;
     a.c_first_nan = p->c_first_nan;
+    a.c_lam = p->c_lam;
     a.out_mom = d_out_moments; a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
     a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
     a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;

@@ -126,7 +126,7 @@ constexpr int kMaxEigIters = 64;
 template <int N, int G>
 __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const int grp,
                                                 const double mean, const double scale, double& x_out, double& w_out,
-                                                double* dbg = nullptr) {
+                                                double& lam_io, double* dbg = nullptr) {
     static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
     // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
     const int li = (l <= N) ? l : N;
@@ -190,7 +190,10 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
         const double tol = 1e-15 * fmax(fabs(lo), fabs(hi));  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
         const int k = (l < N) ? l : N - 1;
+        // start from this lane's eigenvalue of the previous rule when there is one (the Jacobi matrix moves little
+        // between consecutive quadratures), else spread the lanes over the bracket
         double x = lo + (hi - lo) * ((double)k + 0.5) * (1.0 / (double)N);
+        if (lam_io > lo && lam_io < hi) x = lam_io;
         bool conv = false;
         for (int it = 0; it < kMaxEigIters; ++it) {
             double p0 = 1.0, p1 = a[0] - x, d0 = 0.0, d1 = -1.0, e0 = 0.0, e1 = 0.0;
@@ -222,6 +225,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             if (gall<G>(conv, grp)) break;
         }
         lam = x;
+        lam_io = x;
         // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2   (quadtures.py:133, V[0, :]**2)
         double p0 = 1.0, p1 = a[0] - lam, acc = 1.0;
         static_for<1, N>([&](auto Jc) {
@@ -284,15 +288,24 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
     bool dead = (first_nan >= 0);
     const double qnan = __builtin_nan("");
     const bool node = (l < N);
+    // warm starts for the predict / update quadratures; part of the carry so that a chunked run is bit-identical
+    double lamA = qnan, lamB = qnan;
+    if (a.t_begin != 0 && a.c_lam) { lamA = a.c_lam[((size_t)b * 2) * G + l]; lamB = a.c_lam[((size_t)b * 2 + 1) * G + l]; }
+    double ywin = 0.0;                  // 16-step window of measurements, one per lane
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
-        const double y = yrow[t];
+        // measurements: one coalesced 128-byte load per group every 16 steps, handed out by a lane shuffle
+        const int tw = (t - a.t_begin) & 15;
+        if (tw == 0) ywin = (t + (l & 15) < a.t_end) ? yrow[t + (l & 15)] : 0.0;
+        const double y = __shfl(ywin, tw, 16);
         if (!dead) {
             int bad = 0;
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
                 double x, w;
-                quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w);
+                double lam_io = (half == 0) ? lamA : lamB;
+                quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w, lam_io);
+                if (half == 0) lamA = lam_io; else lamB = lam_io;
                 const double u = (a.umap == MFS_U_TANH) ? tanh(x) : x;
                 double c = 0.0, inv_sc = 1.0, py = 1.0;
                 if (half == 0) {
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
         }
     } else {
         for (int n = l; n < M2; n += G) a.c_mom[(size_t)b * M2 + n] = mom[n];
+        if (a.c_lam) { a.c_lam[((size_t)b * 2) * G + l] = lamA; a.c_lam[((size_t)b * 2 + 1) * G + l] = lamB; }
         if (l == 0) {
             a.c_mean[b] = mean; a.c_scale[b] = scale; a.c_nell[b] = nell; a.c_first_nan[b] = first_nan;
         }
@@ -432,9 +446,10 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
     for (int n = l; n < M2; n += G) S[n] = a.ms[(size_t)b * M2 + n];
     wave_sync();
     double x, w;
+    double lam_dummy = __builtin_nan("");
     if (a.stable & 2) {  // debug: return (a_j, b2_j) instead of (w, x)
         __shared__ double dbg[4 * 6 * N];
-        quadrature_fast<N, G>(S, l, grp, 0.0, 1.0, x, w, dbg + slot * 6 * N);
+        quadrature_fast<N, G>(S, l, grp, 0.0, 1.0, x, w, lam_dummy, dbg + slot * 6 * N);
         wave_sync();
         if (l < N) {
             const int sel = a.stable >> 2;  // 0: (a, b2); 1: (iterations, last step); 2: (tol, count)
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
         }
         return;
     }
-    quadrature_fast<N, G>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w);
+    quadrature_fast<N, G>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w, lam_dummy);
     if (l < N) {
         a.out_w[(size_t)b * N + l] = w;
         a.out_x[(size_t)b * N + l] = x;
