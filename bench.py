@@ -185,6 +185,7 @@ def main():
         M = int(transition.rsplit('_', 1)[1])
         flops_step = 22.7 * N ** 3 + (8 * M + 12) * N ** 2
         tflops = live_steps * flops_step / (kern_ms_avg * 1e-3) / 1e12
+        traffic = recorded_hbm_traffic(args.workload, d_mom is not None)
         out = {
             'metric': 'filter time-steps/sec', 'value': value, 'unit': 'filter-steps/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -198,8 +199,10 @@ def main():
             'replicates_alive_at_T': alive_total, 'replicates': world * B, 'nll_allgather_ok': gather_ok,
             'target_1e6_steps_per_s_met': bool(value >= 1e6 * world),
             'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'mfs::filter1d_kernel', 'avg_launch_ms': kern_ms_avg,
+                         'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'mfs::filter1d_fast_kernel', 'avg_launch_ms': kern_ms_avg,
+                         'traffic_source': 'profiles/*/pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+                                           'passes, FETCH_SIZE x2 on gfx950)' if traffic else None,
                          'algorithmic_bytes_per_launch': algo_bytes,
                          'note': 'latency/VALU-bound fp64 recursion, not HBM-bound: see valu_fp64'},
             'valu_fp64': {'achieved': tflops, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -209,6 +212,22 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, nell, first_nan)
         print(json.dumps(out))
     comm.close()
+
+
+def recorded_hbm_traffic(workload, moments_streamed):
+    """HBM bytes per launch from the committed PMC summary of this workload (counters cannot be read from inside the
+    process; they are collected with rocprofv3 --pmc in separate passes and committed under profiles/)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc.json'))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get('workload') == workload and moments_streamed and 'hbm_bytes_per_launch' in rec:
+            best = rec['hbm_bytes_per_launch']
+    return best
 
 
 def cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, dev_nell, dev_first_nan):
