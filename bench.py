@@ -99,7 +99,7 @@ def main():
     model, N, T, B, mode, transition = WORKLOADS[args.workload]
     B = args.B or B
     T = args.T or T
-    comm = dist.Communicator.from_env()  # rendezvous (torch.distributed, gloo) + RCCL communicator for the NLL gather
+    comm = dist.Communicator.from_env()  # TCP control plane (mfs_amd/rdzv.py) + RCCL communicator for the NLL gather
     L = _lib.lib()
     _lib.check(L.mfs_set_device(local_rank))
 
@@ -197,6 +197,8 @@ def main():
                        'moments_streamed_out': d_mom is not None},
             'nominal_value': nominal, 'live_fraction': live_total / nominal_steps,
             'replicates_alive_at_T': alive_total, 'replicates': world * B, 'nll_allgather_ok': gather_ok,
+            'nll_allgather': ('rccl ncclAllGather' if comm.data == 'rccl' and world > 1 else
+                              'single rank: device copy' if world == 1 else f'host fallback: {comm.rccl_error}'),
             'target_1e6_steps_per_s_met': bool(value >= 1e6 * world),
             'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic,

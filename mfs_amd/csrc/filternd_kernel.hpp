@@ -105,7 +105,8 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
 
 // Fills lam[2][NP] and W[S][S]; returns block-uniform poison flag.
 template <int N>
-__device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
+__device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable,
+                              const bool warm) {
     using L = NdTile<N>;
     constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -123,8 +124,10 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         A[i * LD + j] = in ? mom[inds[i * S + j]] : 0.0;
         K[i * LD + j] = in ? mom[inds[S * S + i * S + j]] : 0.0;
         K[NP * LD + i * LD + j] = in ? mom[inds[2 * S * S + i * S + j]] : 0.0;
-        V[i * LD + j] = (i == j) ? 1.0 : 0.0;
-        V[NP * LD + i * LD + j] = (i == j) ? 1.0 : 0.0;
+        if (!warm) {
+            V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+            V[NP * LD + i * LD + j] = (i == j) ? 1.0 : 0.0;
+        }
     }
     if (tid == 0) flags[0] = 0.0;
     __syncthreads();
@@ -205,6 +208,38 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         }
     }
     __syncthreads();
+
+    // -- warm start: the eigenvector matrices of the previous rule are still in LDS.  K changes little between
+    //    consecutive rules, so V_prev^T K V_prev is already nearly diagonal and the sweeps below converge
+    //    quadratically from there (2-3 sweeps instead of 8-9); V then accumulates on top of V_prev.  The tile of the
+    //    Cholesky factor is free by now and serves as the temporary.
+    if (warm) {
+        for (int m = 0; m < 2; ++m) {
+            double* Kk = K + m * NP * LD;
+            const double* Vk = V + m * NP * LD;
+            for (int e = tid; e < S * S; e += nthr) {   // A = K V
+                const int i = e / S, j = e - i * S;
+                double acc = 0.0;
+                for (int k = 0; k < S; ++k) acc = fma(Kk[i * LD + k], Vk[k * LD + j], acc);
+                A[i * LD + j] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < S * S; e += nthr) {   // K = V^T A, symmetrised on the fly
+                const int i = e / S, j = e - i * S;
+                if (i >= j) {
+                    double a1 = 0.0, a2 = 0.0;
+                    for (int k = 0; k < S; ++k) {
+                        a1 = fma(Vk[k * LD + i], A[k * LD + j], a1);
+                        a2 = fma(Vk[k * LD + j], A[k * LD + i], a2);
+                    }
+                    const double v = 0.5 * (a1 + a2);
+                    Kk[i * LD + j] = v;
+                    Kk[j * LD + i] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
 
     // -- cyclic Jacobi on both matrices with eigenvectors (quadratures.py:163)
     double prev_off = 1.79e308;
@@ -328,6 +363,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
     __syncthreads();
     int first_nan = -1;
     bool dead = false;
+    bool warm = false;
     const double qnan = __builtin_nan("");
     const double* yrow = a.ys + (size_t)b * a.T;
 
@@ -338,7 +374,8 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
                 // half 0 = prediction (filtering.py:262-266 / :330-331), half 1 = update (:268-275 / :333-339)
-                const bool poisoned = quadrature_nd<N>(Sm, a.inds, a.stable);
+                const bool poisoned = quadrature_nd<N>(Sm, a.inds, a.stable, warm);
+                warm = !poisoned;
                 const double* lam = Sm + L::oLam;
                 const double* W = Sm + L::oW;
                 const double qm0 = mean0, qm1 = mean1;  // the centre this quadrature's nodes are built around
@@ -373,54 +410,62 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                     if (a.mode != MFS_MODE_RAW) { c0 = s0 / py; c1 = s1 / py; }
                     nell -= log(py);
                 }
-                // ---- pass 2: per-node contributions to all Z moments about the new centre, in registers
-                double acc[Z];
+                // ---- pass 2: every moment about the new centre.  Each thread owns up to two nodes per sweep of the
+                //      node list; for each moment (compile-time multi-index) the two contributions are added and
+                //      reduced across the wave at once, so no per-thread accumulator array exists (it would spill).
+                for (int base = 0; base < R; base += 512) {
+                    double wA, wB, pxA0[P], pxA1[P], pxB0[P], pxB1[P], QA[kNdTerms], QB[kNdTerms];
+                    {
+                        const int eA = base + tid, eB = base + 256 + tid;
+                        const bool okA = eA < R, okB = eB < R;
+                        const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
+                        const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
+                        wA = okA ? W[eA] : 0.0;
+                        wB = okB ? W[eB] : 0.0;
+                        const double xA0 = lam[iA0] + qm0, xA1 = lam[NP + iA1] + qm1;
+                        const double xB0 = lam[iB0] + qm0, xB1 = lam[NP + iB1] + qm1;
+                        pxA0[0] = pxA1[0] = pxB0[0] = pxB1[0] = 1.0;
 #pragma unroll
-                for (int zi = 0; zi < Z; ++zi) acc[zi] = 0.0;
-                for (int e = tid; e < R; e += 256) {
-                    const int i0 = e / S, i1 = e - i0 * S;
-                    double w = W[e];
-                    const double x0 = lam[i0] + qm0, x1 = lam[NP + i1] + qm1;
-                    const double d0 = x0 - c0, d1 = x1 - c1;
-                    double px0[P], px1[P];
-                    px0[0] = 1.0; px1[0] = 1.0;
-#pragma unroll
-                    for (int p = 1; p < P; ++p) { px0[p] = px0[p - 1] * d0; px1[p] = px1[p - 1] * d1; }
-                    if (half == 0) {
-                        double Q[kNdTerms];
-#pragma unroll
-                        for (int k = 0; k < kNdTerms; ++k)
-                            Q[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, x0, x1) : 0.0;
-#pragma unroll
-                        for (int s = 0; s < 2 * N; ++s) {
-#pragma unroll
-                            for (int n0 = 0; n0 <= s; ++n0) {
-                                const int n1 = s - n0, zi = s * (s + 1) / 2 + n0;
-                                double val = px0[n0] * px1[n1];
-#pragma unroll
-                                for (int k = 0; k < kNdTerms; ++k) {
-                                    if (kKap0[k] <= n0 && kKap1[k] <= n1)
-                                        val = fma(Q[k] * (ffact(n0, kKap0[k]) * ffact(n1, kKap1[k])),
-                                                  px0[n0 - kKap0[k]] * px1[n1 - kKap1[k]], val);
-                                }
-                                acc[zi] = fma(w, val, acc[zi]);
-                            }
+                        for (int p = 1; p < P; ++p) {
+                            pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1);
+                            pxB0[p] = pxB0[p - 1] * (xB0 - c0); pxB1[p] = pxB1[p - 1] * (xB1 - c1);
                         }
-                    } else {
-                        w *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
+                        if (half == 0) {
 #pragma unroll
-                        for (int s = 0; s < 2 * N; ++s) {
+                            for (int k = 0; k < kNdTerms; ++k) {
+                                QA[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, xA0, xA1) : 0.0;
+                                QB[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, xB0, xB1) : 0.0;
+                            }
+                        } else {
+                            wA *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
+                            wB *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xB0 : xB1);
 #pragma unroll
-                            for (int n0 = 0; n0 <= s; ++n0)
-                                acc[s * (s + 1) / 2 + n0] = fma(w, px0[n0] * px1[s - n0], acc[s * (s + 1) / 2 + n0]);
+                            for (int k = 0; k < kNdTerms; ++k) { QA[k] = 0.0; QB[k] = 0.0; }
                         }
                     }
-                }
-                // ---- block reduction of the Z accumulators: wave DPP sums, then four partials through LDS
 #pragma unroll
-                for (int zi = 0; zi < Z; ++zi) {
-                    const double v = wave_sum64(acc[zi]);
-                    if ((tid & 63) == 0) red[(tid >> 6) * (Z + 4) + zi] = v;
+                    for (int s = 0; s < 2 * N; ++s) {
+#pragma unroll
+                        for (int n0 = 0; n0 <= s; ++n0) {
+                            const int n1 = s - n0, zi = s * (s + 1) / 2 + n0;
+                            double vA = pxA0[n0] * pxA1[n1], vB = pxB0[n0] * pxB1[n1];
+                            if (half == 0) {
+#pragma unroll
+                                for (int k = 0; k < kNdTerms; ++k) {
+                                    if (kKap0[k] <= n0 && kKap1[k] <= n1) {
+                                        const double ff = ffact(n0, kKap0[k]) * ffact(n1, kKap1[k]);
+                                        vA = fma(QA[k] * ff, pxA0[n0 - kKap0[k]] * pxA1[n1 - kKap1[k]], vA);
+                                        vB = fma(QB[k] * ff, pxB0[n0 - kKap0[k]] * pxB1[n1 - kKap1[k]], vB);
+                                    }
+                                }
+                            }
+                            const double v = wave_sum64(fma(wA, vA, wB * vB));
+                            if ((tid & 63) == 0) {
+                                double* slot = red + (tid >> 6) * (Z + 4) + zi;
+                                *slot = (base == 0) ? v : *slot + v;
+                            }
+                        }
+                    }
                 }
                 __syncthreads();
                 const double ipy = 1.0 / py;
