@@ -115,11 +115,24 @@ struct FastTile {
     static constexpr int oTab = M2;            // [N][2N + 1] per-node contributions (row padded: conflict-free)
     static constexpr int TLD = M2 + 1;
     static constexpr int oLik = oTab + N * TLD;
-    static constexpr int oCoef = (oLik + MFS_MAX_LIK + 1) & ~1;  // model table, n_rows * (degree + 1) doubles
+    static constexpr int oLfac = (oLik + MFS_MAX_LIK + 1) & ~1;  // log(y!) for y = 0..kLfacMax (Poisson likelihood)
+    static constexpr int oCoef = oLfac + 34;                    // model table, n_rows * (degree + 1) doubles
     static constexpr int fixedDoubles = oCoef;
 };
 
 constexpr int kMaxEigIters = 64;
+constexpr int kLfacMax = 32;
+
+// Poisson pmf with log(y!) looked up for the counts that actually occur (y <= 32) instead of a sum of logs per step
+__device__ __forceinline__ double likelihood_fast(const int kind, const double* __restrict__ lp,
+                                                  const double* __restrict__ lfac, const double y, const double x) {
+    if (kind == MFS_LIK_POISSON_SOFTPLUS) {
+        const double rate = log(1.0 + exp(lp[0] * x));
+        const double lf = (y >= 0.0 && y <= (double)kLfacMax && y == floor(y)) ? lfac[(int)y] : log_factorial(y);
+        return exp(y * log(rate) - rate - lf);
+    }
+    return likelihood(kind, lp, y, x);
+}
 
 // Gauss quadrature from the 2N moments in LDS.  Lane l < N returns node x and weight w; other lanes get w = 0.
 // Returns the group-uniform poison flag (a Cholesky pivot was not > 0, as LAPACK potrf / XLA report).
@@ -246,7 +259,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 // the filter kernel (fast path)
 // ---------------------------------------------------------------------------------------------------------------
 template <int N, int G, int WPB>
-__global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
+__global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
     using L = FastTile<N>;
     constexpr int M2 = L::M2, TLD = L::TLD;
     constexpr int FPW = 64 / G;
@@ -268,6 +281,8 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
         for (int e = l; e < a.n_rows * J1; e += G) S[L::oCoef + e] = src[e];
         const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
         for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + e] = (e < a.n_lik) ? ls[e] : 0.0;
+        if (a.lik_kind == MFS_LIK_POISSON_SOFTPLUS)
+            for (int e = l; e <= kLfacMax; e += G) S[L::oLfac + e] = log_factorial((double)e);
     }
     double mean = 0.0, scale = 1.0, nell = 0.0;
     int first_nan = -1;
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(WPB * 64) void filter1d_fast_kernel(const Filter1dA
                     }
                 } else {
                     // ---- update (filtering.py:82-85 / 151-157 / 228-236)
-                    const double wl = node ? w * likelihood(a.lik_kind, lp, y, x) : 0.0;
+                    const double wl = node ? w * likelihood_fast(a.lik_kind, lp, S + L::oLfac, y, x) : 0.0;
                     py = gsum<G>(wl);
                     if (a.mode != MFS_MODE_RAW) {
                         mean = gsum<G>(wl * x) / py;
