@@ -167,6 +167,16 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
                       double* out_weights, double* out_nodes, int device, void* stream);
 
 /*
+ * ---- characteristic function from moments ------------------------------------------------------------------------
+ * Replaces characteristic_fn (mfs/one_dim/moments.py:309-337) as the post-processing drivers call it
+ * (dardel/benes_bernoulli/post_processing_mf.py:37-60: vmapped over the z grid and over every filtering step):
+ * out[c][k] = sum_n w_n exp(i zs[k] x_n) with (w, x) the quadrature of ms[c] (mean / scale [count] or NULL).
+ * ms [count][2N]; zs [nz]; out [count][nz][2] = (re, im) pairs, i.e. a C-contiguous complex128 array.  Host pointers.
+ */
+int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean, const double* scale, int nz,
+                          const double* zs, double* out, int device, void* stream);
+
+/*
  * ---- N-D moment filter (d = 2), host pointers ------------------------------------------------------------------
  * Replaces moment_filter_nd_rms / moment_filter_nd_cms (mfs/multi_dims/filtering.py:283-344, 210-280) with the
  * TME transition of mfs/multi_dims/moments.py:414-479 ('multi-index' signature) for B replicates.  The scaled mode

@@ -73,6 +73,7 @@ _SIGNATURES = [
     ('mfs_plan_1d_geometry', _i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int)]),
     ('mfs_quadrature_1d', _i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    ('mfs_characteristic_1d', _i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     ('mfs_filter_nd', _i, [C.POINTER(MfsModelNd), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i,
                            _vp, _vp, _vp, _vp, _i, _vp]),
     ('mfs_comm_unique_id', _i, [_vp]),

@@ -16,6 +16,8 @@
 namespace mfs {
 KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
 Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
+using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
+Cf1dLaunch g_cf[MFS_MAX_N + 1][3];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
 struct NdEntry { FilterNdLaunch launch; int S, Z, lds_bytes; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
@@ -568,5 +570,43 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     hipFree(d_coef); hipFree(d_lik); hipFree(d_inds); hipFree(d_m0); hipFree(d_mean0); hipFree(d_ys); hipFree(d_mom);
     hipFree(d_means); hipFree(d_nell); hipFree(d_fn);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// characteristic function from moments, host pointers
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean, const double* scale,
+                                     int nz, const double* zs, double* out, int device, void* stream) {
+    if (N < 2 || N > MFS_MAX_N) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, %d]", N, MFS_MAX_N);
+    if (count < 0 || nz < 0) return fail(MFS_EINVAL, "negative count or nz");
+    if (count == 0 || nz == 0) return MFS_OK;
+    if (!ms || !zs || !out) return fail(MFS_EINVAL, "NULL buffer");
+    const int gi = (N + 1 <= 16) ? 0 : (N + 1 <= 32) ? 1 : 2;
+    mfs::Cf1dLaunch launch = mfs::g_cf[N][gi];
+    if (!launch) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t s = (hipStream_t)stream;
+    const int G = (gi == 0) ? 16 : (gi == 1) ? 32 : 64, fpb = 64 / G;
+    double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_zs = nullptr, *d_out = nullptr;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes); };
+    alloc((void**)&d_ms, (size_t)count * 2 * N * 8);
+    alloc((void**)&d_zs, (size_t)nz * 8);
+    alloc((void**)&d_out, (size_t)count * nz * 16);
+    if (mean) alloc((void**)&d_mean, (size_t)count * 8);
+    if (scale) alloc((void**)&d_scale, (size_t)count * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ms, ms, (size_t)count * 2 * N * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_zs, zs, (size_t)nz * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && mean) e = hipMemcpyAsync(d_mean, mean, (size_t)count * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)count * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        mfs::Cf1dArgs a{count, nz, d_ms, d_mean, d_scale, d_zs, d_out};
+        e = launch(a, (count + fpb - 1) / fpb, fpb * 2 * N * 8, s);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)count * nz * 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_ms); hipFree(d_mean); hipFree(d_scale); hipFree(d_zs); hipFree(d_out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_characteristic_1d: %s", hipGetErrorString(e));
     return MFS_OK;
 }

@@ -480,4 +480,51 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// characteristic function from moments: E[exp(i z X)] ~= sum_n w_n exp(i z x_n)
+// (mfs/one_dim/moments.py:309-337; callers dardel/benes_bernoulli/post_processing_mf.py:37-60).  One group per
+// moment vector: the rule comes from quadrature_fast, every lane then holds all N (x, w) pairs and walks the z grid
+// lane-parallel, so the complex outputs of a group are 16 consecutive 16-byte elements (coalesced stores).
+// ---------------------------------------------------------------------------------------------------------------
+struct Cf1dArgs {
+    int count, nz;
+    const double* ms;     // [count][2N]
+    const double* mean;   // [count] or null
+    const double* scale;  // [count] or null
+    const double* zs;     // [nz]
+    double* out;          // [count][nz][2]  (re, im)
+};
+
+template <int N, int G, int WPB>
+__global__ __launch_bounds__(WPB * 64) void cf1d_fast_kernel(const Cf1dArgs a) {
+    constexpr int M2 = 2 * N;
+    constexpr int FPW = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / G, l = lane - grp * G;
+    const int slot = wave * FPW + grp;
+    const int b = blockIdx.x * (WPB * FPW) + slot;
+    if (b >= a.count) return;
+    double* S = smem + (size_t)slot * M2;
+    for (int n = l; n < M2; n += G) S[n] = a.ms[(size_t)b * M2 + n];
+    wave_sync();
+    double x, w, lam = __builtin_nan("");
+    quadrature_fast<N, G>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w, lam);
+    double xs[N], ws[N];
+    static_for<0, N>([&](auto Jc) { xs[Jc] = bcast<G, Jc>(x); ws[Jc] = bcast<G, Jc>(w); });
+    double* dst = a.out + (size_t)b * a.nz * 2;
+    for (int k = l; k < a.nz; k += G) {
+        const double z = a.zs[k];
+        double re = 0.0, im = 0.0;
+        static_for<0, N>([&](auto Jc) {
+            double sn, cn;
+            sincos(z * xs[Jc], &sn, &cn);
+            re = fma(ws[Jc], cn, re);
+            im = fma(ws[Jc], sn, im);
+        });
+        reinterpret_cast<double2*>(dst)[k] = make_double2(re, im);
+    }
+}
+
 }  // namespace mfs

@@ -10,6 +10,8 @@ namespace mfs {
 
 extern KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // defined in capi.hip
 extern Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
+using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
+extern Cf1dLaunch g_cf[MFS_MAX_N + 1][3];
 
 constexpr int kBlockLdsBudget = 64 * 1024;
 
@@ -79,7 +81,14 @@ hipError_t launch_quad_fast(const Quad1dArgs& a, int grid, int lds, hipStream_t 
 }
 
 template <int N, int G>
+hipError_t launch_cf_fast(const Cf1dArgs& a, int grid, int lds, hipStream_t s) {
+    hipLaunchKernelGGL((cf1d_fast_kernel<N, G, 1>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int N, int G>
 void reg_fast(int gi) {
+    g_cf[N][gi] = &launch_cf_fast<N, G>;
     KernelEntry& e = g_table[N][3 + gi];
     g_fast_filter[N][gi] = &launch_filter_fast<N, G>;
     e.filter = nullptr;

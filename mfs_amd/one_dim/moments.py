@@ -14,7 +14,7 @@ from mfs_amd.tme_poly import TransitionTables, tme_tables, euler_tables, normal_
 
 __all__ = ['central_moment_of_normal', 'raw_moment_of_standard_normal', 'raw_moment_of_normal', 'raw_to_central',
            'central_to_raw', 'raw_to_scaled', 'scaled_to_central', 'sde_cond_moments_tme',
-           'sde_cond_moments_tme_normal', 'sde_cond_moments_euler', 'sde_cond_moments_normal']
+           'sde_cond_moments_tme_normal', 'sde_cond_moments_euler', 'sde_cond_moments_normal', 'characteristic_fn']
 
 
 def central_moment_of_normal(variance: float, p: int) -> float:
@@ -163,3 +163,27 @@ def sde_cond_moments_normal(cond_mean: Callable, cond_var: Callable, N: int = No
     m = sym.as_poly(cond_mean(sym.X), 'cond_mean')
     v = sym.as_poly(cond_var(sym.X), 'cond_var')
     return _five(normal_tables(m, v))
+
+
+def characteristic_fn(z, ms, mean=0., scale=1., *, device: int = 0):
+    """Characteristic function computed from moments, E[exp(i z X)] ~= sum_n w_n exp(i z x_n)
+    (mfs/one_dim/moments.py:309-337), on the device.  Vectorised the way the reference's post-processing vmaps it
+    (dardel/benes_bernoulli/post_processing_mf.py:37-60): `z` scalar or (m,), `ms` (..., 2N), `mean` / `scale` scalars or
+    (...,); returns complex128 of shape ms.shape[:-1] + z.shape."""
+    from mfs_amd import _lib
+    z_arr = np.ascontiguousarray(np.atleast_1d(np.asarray(z, dtype=np.float64)))
+    ms = np.asarray(ms, dtype=np.float64)
+    lead = ms.shape[:-1]
+    ms2 = np.ascontiguousarray(ms.reshape(-1, ms.shape[-1]))
+    count, M2 = ms2.shape
+    N = M2 // 2
+    if M2 % 2 or not 2 <= N <= _lib.MAX_N:
+        raise ValueError(f'need 2N moments with 2 <= N <= {_lib.MAX_N}, got {M2}')
+    mean_a = np.ascontiguousarray(np.broadcast_to(np.asarray(mean, dtype=np.float64), lead).reshape(-1))
+    scale_a = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), lead).reshape(-1))
+    out = np.empty((count, z_arr.shape[0]), dtype=np.complex128)
+    _lib.check(_lib.lib().mfs_characteristic_1d(N, count, _lib.ptr(ms2), _lib.ptr(mean_a), _lib.ptr(scale_a),
+                                                z_arr.shape[0], _lib.ptr(z_arr), out.ctypes.data_as(_lib.C.c_void_p),
+                                                device, None))
+    out = out.reshape(lead + z_arr.shape)
+    return out[..., 0] if np.ndim(z) == 0 else out
