@@ -558,6 +558,13 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
         a.mode = mode; a.T = T; a.B = B; a.stable = stable;
         a.n_terms_used = model->n_terms; a.D = model->extent;
         a.lik_kind = model->lik_kind; a.n_lik = model->n_lik; a.lik_component = model->lik_component;
+        for (int k = 0; k < MFS_ND_TERMS; ++k) {  // true extents of each Q_kappa block (trailing zero rows / columns cut)
+            int ea = 0, eb = 0;
+            for (int i = 0; i < model->extent; ++i)
+                for (int j = 0; j < model->extent; ++j)
+                    if (model->coef[(size_t)k * DD + i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
+            a.ext[k] = (ea == 0) ? 0 : (ea | (eb << 8));
+        }
         a.coef = d_coef; a.lik = d_lik; a.inds = d_inds; a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0;
         a.ys = d_ys; a.out_mom = d_mom; a.out_mean = d_means; a.out_nell = d_nell; a.out_first_nan = d_fn;
         e = ke.launch(a, B, s);

@@ -18,10 +18,21 @@
 
 namespace mfs {
 
+#ifdef MFS_ND_STAMPS
+// diagnostic build (scratch/nd_stamps.hip): cycles per phase, accumulated by thread 0 of block 0
+__device__ unsigned long long g_nd_stamps[16];
+#define ND_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_nd_stamps[slot] += now_ - t_last_; t_last_ = now_; } } while (0)
+#define ND_STAMP_BEGIN unsigned long long t_last_ = clock64()
+#else
+#define ND_STAMP(slot) do {} while (0)
+#define ND_STAMP_BEGIN do {} while (0)
+#endif
+
 struct FilterNdArgs {
     int mode, T, B, stable;
     int n_terms_used, D;      // coefficient block extent per variable (degree + 1)
     int lik_kind, n_lik, lik_component;
+    int ext[14];              // per-term true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
     const double* coef;       // [kNdTerms][D][D] in the fixed kappa order below (zeros where the model has no term)
     const double* lik;        // [n_lik]
     const int32_t* inds;      // [3][s][s]
@@ -85,15 +96,32 @@ __device__ __forceinline__ double wave_sum64(double v) {
     return tot;
 }
 
-__device__ __forceinline__ double poly2d(const double* __restrict__ c, const int D, const double x0, const double x1) {
-    // sum_{a,b} c[a][b] x0^a x1^b, nested Horner
+__device__ __forceinline__ double poly2d(const double* __restrict__ c, const int D, const int ext, const double x0,
+                                         const double x1) {
+    // sum_{a < ea, b < eb} c[a][b] x0^a x1^b by nested Horner; ext = ea | eb << 8 are the true extents of this block
+    // (most Q_kappa of a low-order TME have degree <= 2 although the common block is D x D)
+    const int ea = ext & 0xff, eb = ext >> 8;
     double acc = 0.0;
-    for (int a = D - 1; a >= 0; --a) {
-        double row = c[a * D + D - 1];
-        for (int b = D - 2; b >= 0; --b) row = fma(row, x1, c[a * D + b]);
+    for (int a = ea - 1; a >= 0; --a) {
+        double row = c[a * D + eb - 1];
+        for (int b = eb - 2; b >= 0; --b) row = fma(row, x1, c[a * D + b]);
         acc = fma(acc, x0, row);
     }
     return acc;
+}
+
+__device__ __forceinline__ double rcp_nr(const double v) {
+    double y = __builtin_amdgcn_rcp(v);
+    y = fma(fma(-v, y, 1.0), y, y);
+    y = fma(fma(-v, y, 1.0), y, y);
+    return y;
+}
+
+__device__ __forceinline__ double rsq_nr(const double v) {
+    double y = __builtin_amdgcn_rsq(v);
+    y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
+    y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
+    return y;
 }
 
 // pair p of round r in the round-robin tournament on NP players
@@ -117,6 +145,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     double* cs = Sm + L::oCs;
     double* flags = Sm + L::oMisc + 4;
 
+    ND_STAMP_BEGIN;
     // -- gather (quadratures.py:151-152); pad rows / columns are zero, V = I
     for (int e = tid; e < NP * NP; e += nthr) {
         const int i = e / NP, j = e - i * NP;
@@ -132,6 +161,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     if (tid == 0) flags[0] = 0.0;
     __syncthreads();
 
+    ND_STAMP(0);
     // -- Cholesky (quadratures.py:154) or LDL^T completion (mfs/utils.py:495-538)
     if (!stable) {
         for (int j = 0; j < S; ++j) {
@@ -177,6 +207,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         }
     }
 
+    ND_STAMP(1);
     // -- K_k = R^-1 H_k R^-T (quadratures.py:156-161): columns then rows, both matrices at once
     if (tid < 2 * S) {
         double* Kk = K + (tid / S) * NP * LD;
@@ -209,6 +240,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     }
     __syncthreads();
 
+    ND_STAMP(2);
     // -- warm start: the eigenvector matrices of the previous rule are still in LDS.  K changes little between
     //    consecutive rules, so V_prev^T K V_prev is already nearly diagonal and the sweeps below converge
     //    quadratically from there (2-3 sweeps instead of 8-9); V then accumulates on top of V_prev.  The tile of the
@@ -241,6 +273,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         }
     }
 
+    ND_STAMP(3);
     // -- cyclic Jacobi on both matrices with eigenvectors (quadratures.py:163)
     double prev_off = 1.79e308;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
@@ -262,6 +295,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         if (!(off > 1e-31 * dia)) break;
         if (off < 1e-26 * dia && off > 0.25 * prev_off) break;
         prev_off = off;
+#ifdef MFS_ND_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[8] += 1;
+#endif
 
         for (int r = 0; r < NP - 1; ++r) {
             if (tid < 2 * HP) {
@@ -272,53 +308,105 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 const double app = Kk[p * LD + p], aqq = Kk[q * LD + q], apq = Kk[p * LD + q];
                 double c = 1.0, s = 0.0, t = 0.0;
                 if (apq != 0.0) {
-                    const double theta = (aqq - app) / (2.0 * apq);
-                    t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    c = 1.0 / sqrt(t * t + 1.0);
+                    // the rotation through reciprocal / reciprocal-square-root seeds + Newton steps: a third of the
+                    // latency of full-precision divides and square roots, on the critical path of every round
+                    const double theta = (aqq - app) * rcp_nr(2.0 * apq);
+                    const double v = fma(theta, theta, 1.0);
+                    const double root = v * rsq_nr(v);                       // sqrt(theta^2 + 1); inf stays inf
+                    t = copysign(rcp_nr(fabs(theta) + root), theta);
+                    t = finite(root) ? t : 0.0;                               // |theta| huge: no rotation needed
+                    c = rsq_nr(fma(t, t, 1.0));
                     s = t * c;
                 }
                 cs[(m * HP + P) * 3] = c; cs[(m * HP + P) * 3 + 1] = s; cs[(m * HP + P) * 3 + 2] = t;
             }
             __syncthreads();
-            // A <- J^T A J on 2x2 blocks, and V <- V J on row pairs, for both matrices
-            for (int e = tid; e < 2 * HP * HP; e += nthr) {
-                const int m = e / (HP * HP), blk = e - m * HP * HP, P = blk / HP, Q = blk - P * HP;
-                double* Kk = K + m * NP * LD;
-                const double* csm = cs + m * HP * 3;
+            // One straight-line section per thread: its 2x2 block of A <- J^T A J and its two eigenvector row-pairs of
+            // V <- V J.  All LDS reads are issued before any arithmetic so that one latency is exposed, not three.
+            if constexpr (2 * HP * HP <= 256 && 2 * S * HP <= 512) {
+                const bool hasB = tid < 2 * HP * HP;
+                const int mB = hasB ? tid / (HP * HP) : 0, blk = hasB ? tid - mB * HP * HP : 0;
+                const int P = blk / HP, Q = blk - P * HP;
+                double* Kk = K + mB * NP * LD;
+                const double* csB = cs + mB * HP * 3;
                 int p1, p2, q1, q2;
                 tournament_pair<NP>(r, P, p1, p2);
                 tournament_pair<NP>(r, Q, q1, q2);
+                const int e0 = tid, e1 = tid + 256;
+                const bool has0 = e0 < 2 * S * HP, has1 = e1 < 2 * S * HP;
+                const int m0 = has0 ? e0 / (S * HP) : 0, f0 = has0 ? e0 - m0 * S * HP : 0, row0 = f0 / HP, P0 = f0 - row0 * HP;
+                const int m1 = has1 ? e1 / (S * HP) : 0, f1 = has1 ? e1 - m1 * S * HP : 0, row1 = f1 / HP, P1 = f1 - row1 * HP;
+                double* V0p = V + m0 * NP * LD + row0 * LD;
+                double* V1p = V + m1 * NP * LD + row1 * LD;
+                int u0, w0, u1, w1;
+                tournament_pair<NP>(r, P0, u0, w0);
+                tournament_pair<NP>(r, P1, u1, w1);
+                // ---- loads
                 const double a11 = Kk[p1 * LD + q1], a12 = Kk[p1 * LD + q2];
                 const double a21 = Kk[p2 * LD + q1], a22 = Kk[p2 * LD + q2];
+                const double cP = csB[3 * P], sP = csB[3 * P + 1], tP = csB[3 * P + 2];
+                const double cQ = csB[3 * Q], sQ = csB[3 * Q + 1];
+                const double c0 = cs[(m0 * HP + P0) * 3], s0 = cs[(m0 * HP + P0) * 3 + 1];
+                const double c1 = cs[(m1 * HP + P1) * 3], s1 = cs[(m1 * HP + P1) * 3 + 1];
+                const double v0p = V0p[u0], v0q = V0p[w0], v1p = V1p[u1], v1q = V1p[w1];
+                // ---- arithmetic
                 double b11, b12, b21, b22;
                 if (P == Q) {
-                    const double t = csm[3 * P + 2];
-                    b11 = a11 - t * a12; b22 = a22 + t * a12; b12 = 0.0; b21 = 0.0;
+                    b11 = a11 - tP * a12; b22 = a22 + tP * a12; b12 = 0.0; b21 = 0.0;
                 } else {
-                    const double cP = csm[3 * P], sP = csm[3 * P + 1], cQ = csm[3 * Q], sQ = csm[3 * Q + 1];
                     const double r11 = cP * a11 - sP * a21, r21 = sP * a11 + cP * a21;
                     const double r12 = cP * a12 - sP * a22, r22 = sP * a12 + cP * a22;
                     b11 = cQ * r11 - sQ * r12; b12 = sQ * r11 + cQ * r12;
                     b21 = cQ * r21 - sQ * r22; b22 = sQ * r21 + cQ * r22;
                 }
-                Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
-                Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
-            }
-            for (int e = tid; e < 2 * S * HP; e += nthr) {
-                const int m = e / (S * HP), f = e - m * S * HP, row = f / HP, P = f - row * HP;
-                double* Vk = V + m * NP * LD;
-                const double* csm = cs + m * HP * 3;
-                int p, q;
-                tournament_pair<NP>(r, P, p, q);
-                const double c = csm[3 * P], s = csm[3 * P + 1];
-                const double vp = Vk[row * LD + p], vq = Vk[row * LD + q];
-                Vk[row * LD + p] = c * vp - s * vq;
-                Vk[row * LD + q] = s * vp + c * vq;
+                // ---- stores (every item touches only its own elements)
+                if (hasB) {
+                    Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
+                    Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
+                }
+                if (has0) { V0p[u0] = c0 * v0p - s0 * v0q; V0p[w0] = s0 * v0p + c0 * v0q; }
+                if (has1) { V1p[u1] = c1 * v1p - s1 * v1q; V1p[w1] = s1 * v1p + c1 * v1q; }
+            } else {  // larger N: the same work in strided loops
+                for (int e = tid; e < 2 * HP * HP; e += nthr) {
+                    const int m = e / (HP * HP), blk = e - m * HP * HP, P = blk / HP, Q = blk - P * HP;
+                    double* Kk = K + m * NP * LD;
+                    const double* csm = cs + m * HP * 3;
+                    int p1, p2, q1, q2;
+                    tournament_pair<NP>(r, P, p1, p2);
+                    tournament_pair<NP>(r, Q, q1, q2);
+                    const double a11 = Kk[p1 * LD + q1], a12 = Kk[p1 * LD + q2];
+                    const double a21 = Kk[p2 * LD + q1], a22 = Kk[p2 * LD + q2];
+                    double b11, b12, b21, b22;
+                    if (P == Q) {
+                        const double t = csm[3 * P + 2];
+                        b11 = a11 - t * a12; b22 = a22 + t * a12; b12 = 0.0; b21 = 0.0;
+                    } else {
+                        const double cP = csm[3 * P], sP = csm[3 * P + 1], cQ = csm[3 * Q], sQ = csm[3 * Q + 1];
+                        const double r11 = cP * a11 - sP * a21, r21 = sP * a11 + cP * a21;
+                        const double r12 = cP * a12 - sP * a22, r22 = sP * a12 + cP * a22;
+                        b11 = cQ * r11 - sQ * r12; b12 = sQ * r11 + cQ * r12;
+                        b21 = cQ * r21 - sQ * r22; b22 = sQ * r21 + cQ * r22;
+                    }
+                    Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
+                    Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
+                }
+                for (int e = tid; e < 2 * S * HP; e += nthr) {
+                    const int m = e / (S * HP), f = e - m * S * HP, row = f / HP, P = f - row * HP;
+                    double* Vk = V + m * NP * LD;
+                    const double* csm = cs + m * HP * 3;
+                    int p, q;
+                    tournament_pair<NP>(r, P, p, q);
+                    const double c = csm[3 * P], sn = csm[3 * P + 1];
+                    const double vp = Vk[row * LD + p], vq = Vk[row * LD + q];
+                    Vk[row * LD + p] = c * vp - sn * vq;
+                    Vk[row * LD + q] = sn * vp + c * vq;
+                }
             }
             __syncthreads();
         }
     }
     __syncthreads();
+    ND_STAMP(4);
     const bool poisoned = flags[0] != 0.0;
 
     // -- eigenvalues and tensor-product weights (quadratures.py:165-170)
@@ -334,6 +422,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         W[e] = dot * V0[i0] * V1[i1];
     }
     __syncthreads();
+    ND_STAMP(5);
     return poisoned;
 }
 
@@ -376,6 +465,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 // half 0 = prediction (filtering.py:262-266 / :330-331), half 1 = update (:268-275 / :333-339)
                 const bool poisoned = quadrature_nd<N>(Sm, a.inds, a.stable, warm);
                 warm = !poisoned;
+                ND_STAMP_BEGIN;
                 const double* lam = Sm + L::oLam;
                 const double* W = Sm + L::oW;
                 const double qm0 = mean0, qm1 = mean1;  // the centre this quadrature's nodes are built around
@@ -386,8 +476,8 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                     const double w = W[e];
                     const double x0 = lam[i0] + qm0, x1 = lam[NP + i1] + qm1;
                     if (half == 0) {
-                        s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
-                        s1 = fma(w, x1 + poly2d(coef + 0 * DD, a.D, x0, x1), s1);  // kappa = (0, 1)
+                        s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
+                        s1 = fma(w, x1 + poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s1);  // kappa = (0, 1)
                     } else {
                         const double wl = w * likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
                         s0 = fma(wl, x0, s0); s1 = fma(wl, x1, s1); s4 += wl;
@@ -410,6 +500,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                     if (a.mode != MFS_MODE_RAW) { c0 = s0 / py; c1 = s1 / py; }
                     nell -= log(py);
                 }
+                ND_STAMP(6);
                 // ---- pass 2: every moment about the new centre.  Each thread owns up to two nodes per sweep of the
                 //      node list; for each moment (compile-time multi-index) the two contributions are added and
                 //      reduced across the wave at once, so no per-thread accumulator array exists (it would spill).
@@ -433,8 +524,8 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                         if (half == 0) {
 #pragma unroll
                             for (int k = 0; k < kNdTerms; ++k) {
-                                QA[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, xA0, xA1) : 0.0;
-                                QB[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, xB0, xB1) : 0.0;
+                                QA[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xA0, xA1) : 0.0;
+                                QB[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xB0, xB1) : 0.0;
                             }
                         } else {
                             wA *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
@@ -480,6 +571,10 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 bad = bad || poisoned || (red[Z] != 0.0);
                 __syncthreads();
                 if (tid == 0) red[Z] = 0.0;
+                ND_STAMP(7);
+#ifdef MFS_ND_STAMPS
+                if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
+#endif
             }
             bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1);
             if (bad) { dead = true; first_nan = t; }
