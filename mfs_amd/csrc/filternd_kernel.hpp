@@ -164,20 +164,53 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     ND_STAMP(0);
     // -- Cholesky (quadratures.py:154) or LDL^T completion (mfs/utils.py:495-538)
     if (!stable) {
-        for (int j = 0; j < S; ++j) {
-            if (tid >= j && tid < S) {
-                double s = A[tid * LD + j];
-                for (int k = 0; k < j; ++k) s -= A[tid * LD + k] * A[j * LD + k];
-                A[tid * LD + j] = s;
-            }
-            __syncthreads();
-            const double d = A[j * LD + j];
-            const double r = sqrt(d), inv = 1.0 / r;
-            __syncthreads();
-            if (tid == 0 && !(d > 0.0)) flags[0] = 1.0;
-            if (tid >= j && tid < S) A[tid * LD + j] = (tid == j) ? r : A[tid * LD + j] * inv;
-            __syncthreads();
+        // Register-resident front end on ONE wave, no barriers: lane i (< S) owns row i of G -> L; lane c (< 2S) owns
+        // column c of [H_0 | H_1].  Column step j broadcasts L[j][k] with v_readlane (the filter is alone in its
+        // wave, so the source lane is wave-uniform) and uses each broadcast twice: for the Cholesky dot products
+        // and for the forward substitution X = R^-1 [H_0 | H_1] (quadratures.py:156-161, inner solve) fused into
+        // the same sweep.  The outer solve K^T = R^-1 X^T reuses the rows of L after a transpose through the K tiles.
+        if (tid < 64) {
+            const int li = (tid < S) ? tid : S - 1;
+            const int hc = (tid < 2 * S) ? tid : 0, hm = hc / S, hj = hc - hm * S;
+            double Lr[S], xc[S], rinv_u[S];
+            static_for<0, S>([&](auto Jc) { Lr[Jc] = A[li * LD + Jc]; xc[Jc] = K[hm * NP * LD + Jc * LD + hj]; });
+            bool bad = false;
+            static_for<0, S>([&](auto Jc) {
+                constexpr int j = Jc;
+                double s = Lr[j], xa = xc[j];
+                static_for<0, j>([&](auto Kc) {
+                    constexpr int k = Kc;
+                    const double bc = bcast<64, j>(Lr[k]);
+                    s = fma(-Lr[k], bc, s);
+                    xa = fma(-bc, xc[k], xa);
+                });
+                const double pj = bcast<64, j>(s);
+                bad |= !(pj > 0.0);
+                const double rinv = rsq_nr(pj);
+                rinv_u[j] = rinv;
+                Lr[j] = s * rinv;       // row j itself gets sqrt(piv) = piv * rinv
+                xc[j] = xa * rinv;
+            });
+            if (tid == 0 && bad) flags[0] = 1.0;
+            // transpose X through the K tiles: column hc of X_m -> K_m[:, hj]
+            static_for<0, S>([&](auto Jc) { if (tid < 2 * S) K[hm * NP * LD + Jc * LD + hj] = xc[Jc]; });
+            wave_sync();
+            // row hj of X_m is column hj of X_m^T: forward-substitute it, K_m[hj][:] = (R^-1 X_m^T)[:, hj]
+            double yr[S];
+            static_for<0, S>([&](auto Jc) { yr[Jc] = K[hm * NP * LD + hj * LD + Jc]; });
+            static_for<0, S>([&](auto Ic) {
+                constexpr int i = Ic;
+                double acc = yr[i];
+                static_for<0, i>([&](auto Kc) {
+                    constexpr int k = Kc;
+                    acc = fma(-bcast<64, i>(Lr[k]), yr[k], acc);
+                });
+                yr[i] = acc * rinv_u[i];
+            });
+            wave_sync();
+            static_for<0, S>([&](auto Jc) { if (tid < 2 * S) K[hm * NP * LD + hj * LD + Jc] = yr[Jc]; });
         }
+        __syncthreads();
     } else {
         double fro = 0.0;
         for (int e = tid; e < S * S; e += nthr) { const double v = A[(e / S) * LD + (e % S)]; fro += v * v; }
@@ -205,30 +238,30 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             if (tid >= j && tid < S) A[tid * LD + j] = (tid == j) ? fj : A[tid * LD + j] * fj;
             __syncthreads();
         }
+        // -- K_k = R^-1 H_k R^-T (quadratures.py:156-161): columns then rows, both matrices at once
+        if (tid < 2 * S) {
+            double* Kk = K + (tid / S) * NP * LD;
+            const int c = tid % S;
+            for (int i = 0; i < S; ++i) {
+                double s = Kk[i * LD + c];
+                for (int k = 0; k < i; ++k) s -= A[i * LD + k] * Kk[k * LD + c];
+                Kk[i * LD + c] = s / A[i * LD + i];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * S) {
+            double* Kk = K + (tid / S) * NP * LD;
+            const int i = tid % S;
+            for (int j = 0; j < S; ++j) {
+                double s = Kk[i * LD + j];
+                for (int k = 0; k < j; ++k) s -= Kk[i * LD + k] * A[j * LD + k];
+                Kk[i * LD + j] = s / A[j * LD + j];
+            }
+        }
+        __syncthreads();
     }
 
     ND_STAMP(1);
-    // -- K_k = R^-1 H_k R^-T (quadratures.py:156-161): columns then rows, both matrices at once
-    if (tid < 2 * S) {
-        double* Kk = K + (tid / S) * NP * LD;
-        const int c = tid % S;
-        for (int i = 0; i < S; ++i) {
-            double s = Kk[i * LD + c];
-            for (int k = 0; k < i; ++k) s -= A[i * LD + k] * Kk[k * LD + c];
-            Kk[i * LD + c] = s / A[i * LD + i];
-        }
-    }
-    __syncthreads();
-    if (tid < 2 * S) {
-        double* Kk = K + (tid / S) * NP * LD;
-        const int i = tid % S;
-        for (int j = 0; j < S; ++j) {
-            double s = Kk[i * LD + j];
-            for (int k = 0; k < j; ++k) s -= Kk[i * LD + k] * A[j * LD + k];
-            Kk[i * LD + j] = s / A[j * LD + j];
-        }
-    }
-    __syncthreads();
     for (int e = tid; e < 2 * S * S; e += nthr) {
         double* Kk = K + (e / (S * S)) * NP * LD;
         const int f = e % (S * S), i = f / S, j = f - i * S;
