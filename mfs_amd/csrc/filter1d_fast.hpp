@@ -29,6 +29,16 @@
 
 namespace mfs {
 
+#ifdef MFS_1D_STAMPS
+// diagnostic build only (scratch/): cycles per phase accumulated by lane 0 of block 0
+__device__ unsigned long long g_1d_stamps[16];
+#define F1_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_1d_stamps[slot] += now_ - t_last_; t_last_ = now_; } } while (0)
+#define F1_STAMP_BEGIN unsigned long long t_last_ = clock64()
+#else
+#define F1_STAMP(slot) do {} while (0)
+#define F1_STAMP_BEGIN do {} while (0)
+#endif
+
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < E) {
@@ -108,6 +118,20 @@ __device__ __forceinline__ void horner_rows(const double* __restrict__ table, co
     }
 }
 
+__device__ __forceinline__ double rcp_nr(const double v) {
+    double y = __builtin_amdgcn_rcp(v);
+    y = fma(fma(-v, y, 1.0), y, y);
+    y = fma(fma(-v, y, 1.0), y, y);
+    return y;
+}
+
+__device__ __forceinline__ double rsq_nr(const double v) {
+    double y = __builtin_amdgcn_rsq(v);
+    y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
+    y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
+    return y;
+}
+
 template <int N>
 struct FastTile {
     static constexpr int M2 = 2 * N;
@@ -122,6 +146,10 @@ struct FastTile {
 
 constexpr int kMaxEigIters = 64;
 constexpr int kLfacMax = 32;
+#ifndef MFS_LAG_STOP
+#define MFS_LAG_STOP 1e-6
+#endif
+constexpr double kLagStop = MFS_LAG_STOP;
 
 // Poisson pmf with log(y!) looked up for the counts that actually occur (y <= 32) instead of a sum of logs per step
 __device__ __forceinline__ double likelihood_fast(const int kind, const double* __restrict__ lp,
@@ -141,11 +169,13 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                                                 const double mean, const double scale, double& x_out, double& w_out,
                                                 double& lam_io, double* dbg = nullptr) {
     static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
+    F1_STAMP_BEGIN;
     // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
     const int li = (l <= N) ? l : N;
     double g[N];
     static_for<0, N>([&](auto J) { g[J] = mom[li + J]; });
 
+    F1_STAMP(0);
     // -- Cholesky, row per lane, left-looking by column (quadtures.py:127); L[j][k] reaches the other lanes by DPP
     double Lr[N];
     double piv[N], sub[N], ipiv[N];  // group-uniform
@@ -169,6 +199,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         Lr[j] = s * rinv;
     });
 
+    F1_STAMP(1);
     // -- Jacobi matrix: a_j = K_jj, b2_j = K_{j+1,j}^2, and the weight normalisers c_j = piv_0 / piv_j
     double a[N], b2[N], c[N];
     double amin = 1.79e308, amax = -1.79e308, bmax2 = 0.0;
@@ -191,6 +222,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     if (dbg) {  // diagnostics: the Jacobi matrix this lane's group derived
         static_for<0, N>([&](auto Jc) { if (l == 0) { dbg[Jc] = a[Jc]; dbg[N + Jc] = b2[Jc]; } });
     }
+    F1_STAMP(2);
     double lam = 0.0, w = 0.0;
     if (!poisoned) {
         // -- eigenvalue k by Sturm counts + Laguerre iteration on the characteristic polynomial p_N (Li & Zeng 1994):
@@ -201,44 +233,65 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         const double rad = 2.0 * sqrt(bmax2);
         const double width = (amax - amin) + 2.0 * rad;
         double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
-        const double tol = 1e-15 * fmax(fabs(lo), fabs(hi));  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
+        const double wscale = fmax(fabs(lo), fabs(hi));
+        const double tol = 1e-15 * wscale;  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
         const int k = (l < N) ? l : N - 1;
         // start from this lane's eigenvalue of the previous rule when there is one (the Jacobi matrix moves little
         // between consecutive quadratures), else spread the lanes over the bracket
         double x = lo + (hi - lo) * ((double)k + 0.5) * (1.0 / (double)N);
         if (lam_io > lo && lam_io < hi) x = lam_io;
         bool conv = false;
+        double prev_step = 0.0;
         for (int it = 0; it < kMaxEigIters; ++it) {
+#ifdef MFS_1D_STAMPS
+            if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[10] += 1;
+#endif
             double p0 = 1.0, p1 = a[0] - x, d0 = 0.0, d1 = -1.0, e0 = 0.0, e1 = 0.0;
-            int cnt = (p1 < 0.0) ? 1 : 0;
+            // Sturm count = number of sign changes along p_0..p_N, taken from the sign bits with integer VALU ops
+            // (a floating-point compare per step would bounce through SGPR masks next to the recurrence's chain)
+            unsigned sgn = (unsigned)__double2hiint(p1) >> 31;
+            int cnt = (int)sgn;                            // p_0 = 1 > 0: a negative p_1 is the first change
             static_for<1, N>([&](auto Jc) {
                 constexpr int j = Jc;
                 const double t = a[j] - x;
                 const double pn = fma(t, p1, -b2[j - 1] * p0);
                 const double dn = fma(t, d1, fma(-b2[j - 1], d0, -p1));
                 const double en = fma(t, e1, fma(-b2[j - 1], e0, -2.0 * d1));
-                cnt += ((pn < 0.0) != (p1 < 0.0)) ? 1 : 0;
+                const unsigned sn = (unsigned)__double2hiint(pn) >> 31;
+                cnt += (int)(sn ^ sgn);
+                sgn = sn;
                 p0 = p1; p1 = pn; d0 = d1; d1 = dn; e0 = e1; e1 = en;
             });
             if (!conv) {  // a converged lane is frozen
                 if (cnt <= k) lo = x; else hi = x;
                 const double mid = 0.5 * (lo + hi);
                 // S = sqrt((N-1) ((N-1) p'^2 - N p p'')) >= 0 for real-rooted p (clamped against rounding)
-                const double disc = (double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)N * p1 * e1);
-                const double S = copysign(sqrt(fmax(disc, 0.0)), p1);
+                // (the step only has to be accurate enough to converge: seeds + Newton steps instead of full-precision
+                //  sqrt / divide; the accuracy of the root comes from the recurrence evaluation, not from the step)
+                const double disc = fmax((double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)N * p1 * e1), 0.0);
+                const double S = copysign(disc > 0.0 ? disc * rsq_nr(disc) : 0.0, p1);
                 const bool right = (cnt == k), left = (cnt == k + 1);
                 const double den = right ? (d1 - S) : (d1 + S);
-                double xn = x - (double)N * p1 / den;
+                double xn = x - (double)N * p1 * rcp_nr(den);
                 const bool ok = (right && xn >= x && xn < hi) || (left && xn <= x && xn > lo);  // false for NaN
                 if (dbg && l < N) { dbg[2 * N + l] = (double)it; dbg[3 * N + l] = xn - x; dbg[4 * N + l] = tol; dbg[5 * N + l] = (double)cnt; }
                 xn = ok ? xn : mid;
-                conv = (ok && fabs(xn - x) <= tol) || (hi - lo <= tol) || (p1 == 0.0 && (right || left));
+                // Laguerre converges cubically near its root: e_next ~ e^3 / gap^2 with gap >~ W / N, so a step below
+                // 1e-6 W lands within ~N^2 1e-18 W of the root and the confirming evaluation can be skipped -- but only
+                // with evidence of that regime: a small step also occurs right after leaving the neighbourhood of a
+                // DIFFERENT root (steps then grow by ~N/(N-2) per iteration).  Hence: small AND at least 100x smaller
+                // than the previous Laguerre step of this lane.
+                const double step = fabs(xn - x);
+                conv = (ok && step <= tol) || (ok && step <= kLagStop * wscale && step <= 1e-2 * prev_step) ||
+                       (hi - lo <= tol) || (p1 == 0.0 && (right || left));
+                prev_step = ok ? step : 0.0;
                 x = xn;
             }
             if (gall<G>(conv, grp)) break;
         }
         lam = x;
         lam_io = x;
+        F1_STAMP(3);
         // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2   (quadtures.py:133, V[0, :]**2)
         double p0 = 1.0, p1 = a[0] - lam, acc = 1.0;
         static_for<1, N>([&](auto Jc) {
@@ -248,6 +301,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             p0 = p1; p1 = pn;
         });
         w = 1.0 / acc;
+        F1_STAMP(4);
     }
     const double qnan = __builtin_nan("");
     x_out = poisoned ? qnan : ((l < N) ? fma(scale, lam, mean) : mean);
@@ -321,6 +375,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                 double lam_io = (half == 0) ? lamA : lamB;
                 quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w, lam_io);
                 if (half == 0) lamA = lam_io; else lamB = lam_io;
+                F1_STAMP_BEGIN;
                 const double u = (a.umap == MFS_U_TANH) ? tanh(x) : x;
                 double c = 0.0, inv_sc = 1.0, py = 1.0;
                 if (half == 0) {
@@ -360,9 +415,11 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                         const double dx = x - c;
                         double sc_n = w;
                         for (int n = 0; n < M2; ++n) {
-                            double val = 0.0;
-#pragma unroll
-                            for (int k = MFS_MAX_TERMS; k >= 0; --k) val = fma(Q[k], D[k], val);
+                            // three independent partial sums: the 9-term dot product is not one dependent FMA chain
+                            double v0 = Q[0] * D[0], v1 = Q[1] * D[1], v2 = Q[2] * D[2];
+                            v0 = fma(Q[3], D[3], v0); v1 = fma(Q[4], D[4], v1); v2 = fma(Q[5], D[5], v2);
+                            v0 = fma(Q[6], D[6], v0); v1 = fma(Q[7], D[7], v1); v2 = fma(Q[8], D[8], v2);
+                            const double val = (v0 + v1) + v2;
                             if (node) row[n] = sc_n * val;
                             sc_n *= inv_sc;
 #pragma unroll
@@ -405,6 +462,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                     }
                     nell -= log(py);
                 }
+                F1_STAMP(5 + half);
                 wave_sync();
                 const double ipy = 1.0 / py;
                 for (int n = l; n < M2; n += G) {
@@ -416,6 +474,10 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                     bad |= !finite(acc);
                 }
                 wave_sync();
+                F1_STAMP(7);
+#ifdef MFS_1D_STAMPS
+                if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[9] += 1;
+#endif
             }
             bad |= (int)(!finite(nell) || !finite(mean) || !finite(scale));
             if (gany<G>(bad != 0, grp)) { dead = true; first_nan = t; }

@@ -110,20 +110,6 @@ __device__ __forceinline__ double poly2d(const double* __restrict__ c, const int
     return acc;
 }
 
-__device__ __forceinline__ double rcp_nr(const double v) {
-    double y = __builtin_amdgcn_rcp(v);
-    y = fma(fma(-v, y, 1.0), y, y);
-    y = fma(fma(-v, y, 1.0), y, y);
-    return y;
-}
-
-__device__ __forceinline__ double rsq_nr(const double v) {
-    double y = __builtin_amdgcn_rsq(v);
-    y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
-    y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
-    return y;
-}
-
 // pair p of round r in the round-robin tournament on NP players
 template <int NP>
 __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p, int& q) {
