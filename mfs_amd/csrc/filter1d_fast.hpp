@@ -132,6 +132,33 @@ __device__ __forceinline__ double rsq_nr(const double v) {
     return y;
 }
 
+// weighted TME moments of one node for all orders n < M2 (see the call site); KT = number of operator terms
+template <int KT, int M2>
+__device__ __forceinline__ void operator_moments(const double (&rows)[MFS_MAX_TERMS + 1], const double dx,
+                                                 const double w, const double inv_sc, const bool node,
+                                                 double* __restrict__ row) {
+    double Qp[KT + 1], E[KT + 1];
+    Qp[0] = 1.0; E[0] = 1.0;
+    double fact = 1.0;
+#pragma unroll
+    for (int k = 1; k <= KT; ++k) { fact *= (double)k; Qp[k] = rows[k - 1] * fact; E[k] = 0.0; }
+    double sc_n = w;
+    for (int n = 0; n < M2; ++n) {
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;  // independent partial sums: no single long FMA chain
+#pragma unroll
+        for (int k = 0; k <= KT; ++k) {
+            if (k % 3 == 0) v0 = fma(Qp[k], E[k], v0);
+            else if (k % 3 == 1) v1 = fma(Qp[k], E[k], v1);
+            else v2 = fma(Qp[k], E[k], v2);
+        }
+        if (node) row[n] = sc_n * ((v0 + v1) + v2);
+        sc_n *= inv_sc;
+#pragma unroll
+        for (int k = KT; k >= 1; --k) E[k] = fma(dx, E[k], E[k - 1]);
+        E[0] *= dx;
+    }
+}
+
 template <int N>
 struct FastTile {
     static constexpr int M2 = 2 * N;
@@ -403,28 +430,20 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                     }
                     double* row = TAB + (node ? l : 0) * TLD;
                     if (a.trans_kind == MFS_TRANS_OPERATOR) {
-                        // E[(X'-c)^n | x] = sum_k Q_k(u) D_k(n), D_k(n) = n!/(n-k)! (x-c)^(n-k), advanced in n by
-                        // D_k(n+1) = dx D_k(n) + k D_{k-1}(n)                               (moments.py:141-179)
-                        double Q[MFS_MAX_TERMS + 1], D[MFS_MAX_TERMS + 1];
-                        Q[0] = 1.0; D[0] = 1.0;
+                        // E[(X'-c)^n | x] = sum_k Q_k(u) n!/(n-k)! (x-c)^(n-k) = sum_k (k! Q_k) C(n,k) dx^(n-k);
+                        // E_k(n) = C(n,k) dx^(n-k) advances in n by Pascal's rule E_k(n+1) = dx E_k(n) + E_{k-1}(n)
+                        // (moments.py:141-179).  Unrolled for the number of operator terms the model really has.
+                        switch (a.n_terms) {
+                            case 2: operator_moments<2, M2>(rows, x - c, w, inv_sc, node, row); break;
+                            case 4: operator_moments<4, M2>(rows, x - c, w, inv_sc, node, row); break;
+                            case 6: operator_moments<6, M2>(rows, x - c, w, inv_sc, node, row); break;
+                            default: {  // any other term count: zero the rows that are not operator terms (row K = variance)
+                                double rq[MFS_MAX_TERMS + 1];
 #pragma unroll
-                        for (int k = 1; k <= MFS_MAX_TERMS; ++k) {
-                            Q[k] = (k <= a.n_terms) ? rows[k - 1] : 0.0;
-                            D[k] = 0.0;
-                        }
-                        const double dx = x - c;
-                        double sc_n = w;
-                        for (int n = 0; n < M2; ++n) {
-                            // three independent partial sums: the 9-term dot product is not one dependent FMA chain
-                            double v0 = Q[0] * D[0], v1 = Q[1] * D[1], v2 = Q[2] * D[2];
-                            v0 = fma(Q[3], D[3], v0); v1 = fma(Q[4], D[4], v1); v2 = fma(Q[5], D[5], v2);
-                            v0 = fma(Q[6], D[6], v0); v1 = fma(Q[7], D[7], v1); v2 = fma(Q[8], D[8], v2);
-                            const double val = (v0 + v1) + v2;
-                            if (node) row[n] = sc_n * val;
-                            sc_n *= inv_sc;
-#pragma unroll
-                            for (int k = MFS_MAX_TERMS; k >= 1; --k) D[k] = fma(dx, D[k], (double)k * D[k - 1]);
-                            D[0] *= dx;
+                                for (int k = 0; k <= MFS_MAX_TERMS; ++k) rq[k] = (k < a.n_terms) ? rows[k] : 0.0;
+                                operator_moments<MFS_MAX_TERMS, M2>(rq, x - c, w, inv_sc, node, row);
+                                break;
+                            }
                         }
                     } else {
                         // normal closure: E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n-1) v E_{n-2}   (moments.py:70-74)
