@@ -44,7 +44,7 @@ def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=5)
-    p.add_argument('--warmup', type=int, default=1)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument('--workload', type=str, default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     p.add_argument('--B', type=int, default=0, help='override replicates per GPU')
     p.add_argument('--T', type=int, default=0, help='override time steps')
