@@ -192,7 +192,7 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     if (N < 2 || N > MFS_MAX_N) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, %d]", N, MFS_MAX_N);
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (chunk < 0) return fail(MFS_EINVAL, "negative chunk");
-    const int slot = pick_slot(N, stable & 1);
+    const int slot = pick_slot(N, stable);
     const mfs::KernelEntry& ke = mfs::g_table[N][slot];
     if (!ke.quad) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
     HIP_TRY(hipSetDevice(device));
@@ -379,7 +379,7 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     if (B < 0) return fail(MFS_EINVAL, "negative B");
     if (B == 0) return MFS_OK;
     if (!ms || !out_weights || !out_nodes) return fail(MFS_EINVAL, "NULL buffer");
-    const int slot = pick_slot(N, stable & 1);
+    const int slot = pick_slot(N, stable);
     const mfs::KernelEntry& ke = mfs::g_table[N][slot];
     if (!ke.quad) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
     HIP_TRY(hipSetDevice(device));

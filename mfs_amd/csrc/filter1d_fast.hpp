@@ -194,7 +194,7 @@ __device__ __forceinline__ double likelihood_fast(const int kind, const double* 
 template <int N, int G>
 __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const int grp,
                                                 const double mean, const double scale, double& x_out, double& w_out,
-                                                double& lam_io, double* dbg = nullptr) {
+                                                double& lam_io) {
     static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
     F1_STAMP_BEGIN;
     // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
@@ -246,9 +246,6 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         amax = fmax(amax, aj);
     });
 
-    if (dbg) {  // diagnostics: the Jacobi matrix this lane's group derived
-        static_for<0, N>([&](auto Jc) { if (l == 0) { dbg[Jc] = a[Jc]; dbg[N + Jc] = b2[Jc]; } });
-    }
     F1_STAMP(2);
     double lam = 0.0, w = 0.0;
     if (!poisoned) {
@@ -301,7 +298,6 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                 const double den = right ? (d1 - S) : (d1 + S);
                 double xn = x - (double)N * p1 * rcp_nr(den);
                 const bool ok = (right && xn >= x && xn < hi) || (left && xn <= x && xn > lo);  // false for NaN
-                if (dbg && l < N) { dbg[2 * N + l] = (double)it; dbg[3 * N + l] = xn - x; dbg[4 * N + l] = tol; dbg[5 * N + l] = (double)cnt; }
                 xn = ok ? xn : mid;
                 // Laguerre converges cubically near its root: e_next ~ e^3 / gap^2 with gap >~ W / N, so a step below
                 // 1e-6 W lands within ~N^2 1e-18 W of the root and the confirming evaluation can be skipped -- but only
@@ -543,17 +539,6 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
     wave_sync();
     double x, w;
     double lam_dummy = __builtin_nan("");
-    if (a.stable & 2) {  // debug: return (a_j, b2_j) instead of (w, x)
-        __shared__ double dbg[4 * 6 * N];
-        quadrature_fast<N, G>(S, l, grp, 0.0, 1.0, x, w, lam_dummy, dbg + slot * 6 * N);
-        wave_sync();
-        if (l < N) {
-            const int sel = a.stable >> 2;  // 0: (a, b2); 1: (iterations, last step); 2: (tol, count)
-            a.out_w[(size_t)b * N + l] = dbg[slot * 6 * N + 2 * sel * N + l];
-            a.out_x[(size_t)b * N + l] = dbg[slot * 6 * N + (2 * sel + 1) * N + l];
-        }
-        return;
-    }
     quadrature_fast<N, G>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w, lam_dummy);
     if (l < N) {
         a.out_w[(size_t)b * N + l] = w;

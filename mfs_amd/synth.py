@@ -33,7 +33,8 @@ def benes_bernoulli_batch(B: int, T: int, dt: float = 1e-2, seed: int = 0, subst
     """ys[b, k] ~ Bernoulli(1 / (1 + exp(-x^3 / slope))) along a Benes path dx = tanh(x) dt + dW. Returns (ys, xs)."""
     rng = np.random.default_rng(seed)
     xs = _euler_path(rng, _mixture_x0(rng, B), np.tanh, T, dt, substeps)
-    p = 1. / (1. + np.exp(-xs ** 3 / slope))
+    with np.errstate(over='ignore'):  # |x| ~ 10 at T = 1000: exp overflows to inf, p -> 0 exactly as intended
+        p = 1. / (1. + np.exp(-xs ** 3 / slope))
     ys = (rng.random((B, T)) < p).astype(np.float64)
     return ys, xs
 

@@ -1,0 +1,21 @@
+import sys, os, ctypes as C, numpy as np
+sys.path.insert(0, '.')
+from mfs_amd import _lib, synth
+_lib.LIB_PATH = os.path.abspath('tools/diag/libmfs_stamps.so')
+from mfs_amd.one_dim import filtering, moments, ss_models
+N, T, B = 15, 200, 64
+dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+_, c, _, mu, _ = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=100)
+m, means, nell, fn = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys, return_first_nan=True)
+st = (C.c_ulonglong * 16)()
+L = _lib.lib(); L.mfs_debug_stamps.argtypes = [C.c_void_p]; print('rc', L.mfs_debug_stamps(st))
+st = np.array(list(st), dtype=np.float64)
+names = ['hankel gather', 'cholesky', 'jacobi coeffs', 'laguerre', 'weights', 'predict contributions', 'update contributions', 'moment reduction']
+halves = st[9]
+print('filter 0 first_nan', fn[0], 'half-steps', halves, 'laguerre iterations per quadrature', st[10] / halves)
+tot = st[:8].sum()
+for i, n in enumerate(names):
+    per = st[i] / (halves if i not in (5, 6) else halves / 2)
+    print(f'{n:24s} {per:9.0f} cycles per occurrence   {100 * st[i] / tot:5.1f} % of stamped')
+print('stamped cycles per step', tot / (halves / 2))
