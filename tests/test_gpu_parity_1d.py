@@ -256,3 +256,38 @@ def test_routines_equivalence_on_device():
     npt.assert_array_almost_equal(rmss[:, 2] - rmss[:, 1] ** 2, scales ** 2, decimal=11)
     for nell in (nell_s, nell_c):
         npt.assert_array_almost_equal(nell_r, nell, decimal=10)
+
+
+@pytest.mark.parametrize('N', [3, 7, 12, 15])
+def test_fast_and_dense_device_paths_agree(N, monkeypatch):
+    """The default register-resident path (Jacobi matrix from the Cholesky pivots + tridiagonal Laguerre eigensolve) and
+    the dense LDS path (both triangular solves in full + cyclic Jacobi on the dense K) are two independent device
+    implementations of mfs/one_dim/quadtures.py:122-133; they must agree far inside the 1e-6 parity bar."""
+    dt, ic, pmf, dev, oic, opmf, ora = _benes(N, 3)
+    T, B = 120, 6
+    ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=40 + N)
+    monkeypatch.delenv('MFS_SOLVER', raising=False)
+    m_f, means_f, nell_f, fn_f = filtering.moment_filter_cms(dev[1], dev[3], pmf, ic.cms, ic.mean, ys,
+                                                             return_first_nan=True)
+    monkeypatch.setenv('MFS_SOLVER', 'dense')
+    m_d, means_d, nell_d, fn_d = filtering.moment_filter_cms(dev[1], dev[3], pmf, ic.cms, ic.mean, ys,
+                                                             return_first_nan=True)
+    both = (fn_f < 0) & (fn_d < 0)
+    assert both.sum() >= B - 2
+    npt.assert_allclose(nell_f[both], nell_d[both], rtol=1e-8)
+    npt.assert_allclose(means_f[both], means_d[both], rtol=1e-7, atol=1e-10)
+    for b in np.where(both)[0]:
+        _assert_moments(m_f[b], m_d[b], rtol=1e-6)
+    # quadrature level, incl. the N = 16..32 instantiations of both paths
+    for Nq in (N, N + 16):
+        rms = np.array([[float(o.raw_moment_of_normal(0.1, 0.9, p)) for p in range(2 * Nq)]])
+        cms = o.raw_to_central(rms[0])[None, :]
+        monkeypatch.delenv('MFS_SOLVER', raising=False)
+        w1, x1 = quadtures.moment_quadrature(cms, 0.1)
+        monkeypatch.setenv('MFS_SOLVER', 'dense')
+        w2, x2 = quadtures.moment_quadrature(cms, 0.1)
+        i1, i2 = np.argsort(x1[0]), np.argsort(x2[0])
+        tol = 1e-10 if Nq <= 12 else 1e-7 if Nq <= 20 else 1e-3
+        npt.assert_allclose(x1[0][i1], x2[0][i2], rtol=tol, atol=tol)
+        big = w2[0][i2] > 1e-8
+        npt.assert_allclose(w1[0][i1][big], w2[0][i2][big], rtol=max(tol, 1e-9) * 10)
