@@ -15,9 +15,9 @@
 
 namespace mfs {
 KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
-Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
+Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
-Cf1dLaunch g_cf[MFS_MAX_N + 1][3];
+Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
 struct NdEntry { FilterNdLaunch launch; int S, Z, lds_bytes; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
@@ -79,10 +79,11 @@ int pick_slot(int N, int stable) {
         else if (want == 16 && N <= 16) gi = 0;
         return gi;
     }
-    int gi = (N + 1 <= 16) ? 0 : (N + 1 <= 32) ? 1 : 2;
+    int gi = (N + 1 <= 8) ? 3 : (N + 1 <= 16) ? 0 : (N + 1 <= 32) ? 1 : 2;
     if (want == 64) gi = 2;
     else if (want == 32 && N + 1 <= 32) gi = 1;
     else if (want == 16 && N + 1 <= 16) gi = 0;
+    else if (want == 8 && N + 1 <= 8) gi = 3;
     return 3 + gi;
 }
 
@@ -589,12 +590,12 @@ extern "C" int mfs_characteristic_1d(int N, int count, const double* ms, const d
     if (count < 0 || nz < 0) return fail(MFS_EINVAL, "negative count or nz");
     if (count == 0 || nz == 0) return MFS_OK;
     if (!ms || !zs || !out) return fail(MFS_EINVAL, "NULL buffer");
-    const int gi = (N + 1 <= 16) ? 0 : (N + 1 <= 32) ? 1 : 2;
+    const int gi = (N + 1 <= 8) ? 3 : (N + 1 <= 16) ? 0 : (N + 1 <= 32) ? 1 : 2;
     mfs::Cf1dLaunch launch = mfs::g_cf[N][gi];
     if (!launch) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
     HIP_TRY(hipSetDevice(device));
     hipStream_t s = (hipStream_t)stream;
-    const int G = (gi == 0) ? 16 : (gi == 1) ? 32 : 64, fpb = 64 / G;
+    const int G = (gi == 3) ? 8 : (gi == 0) ? 16 : (gi == 1) ? 32 : 64, fpb = 64 / G;
     double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_zs = nullptr, *d_out = nullptr;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes); };

@@ -52,6 +52,11 @@ template <int G, int J>
 __device__ __forceinline__ double bcast(double v) {
     if constexpr (G == 16) {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);  // v_mov_b64_dpp row_newbcast:J
+    } else if constexpr (G == 8) {
+        // two filters share a DPP row: lane J of the lower or of the upper half, picked by this lane's half
+        const double lo = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);
+        const double hi = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + 8 + J, 0xf, 0xf, false);
+        return (__lane_id() & 8) ? hi : lo;
     } else if constexpr (G == 64) {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), J);
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
@@ -79,6 +84,11 @@ __device__ __forceinline__ double gsum(double v) {
         v += dpp_move<0x141>(v);  // row_half_mirror
         v += dpp_move<0x140>(v);  // row_mirror
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150, 0xf, 0xf, false);  // lane 0's sum to every lane
+    } else if constexpr (G == 8) {
+        v += dpp_move<0xB1>(v);
+        v += dpp_move<0x4E>(v);
+        v += dpp_move<0x141>(v);  // row_half_mirror: the other quad of this half-row
+        return bcast<8, 0>(v);
     } else {
         return group_sum<G>(v);
     }
@@ -91,7 +101,7 @@ __device__ __forceinline__ bool gall(bool flag, int grp) {
         return __builtin_amdgcn_ballot_w64(!flag) == 0ull;
     } else {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
-        const unsigned long long want = ((G == 32) ? 0xffffffffull : 0xffffull) << (grp * G);
+        const unsigned long long want = ((G == 32) ? 0xffffffffull : (G == 16) ? 0xffffull : 0xffull) << (grp * G);
         return (m & want) == want;
     }
 }
@@ -100,7 +110,7 @@ template <int G>
 __device__ __forceinline__ bool gany(bool flag, int grp) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(flag);
     if constexpr (G == 64) return m != 0ull;
-    const unsigned long long want = ((G == 32) ? 0xffffffffull : 0xffffull) << (grp * G);
+    const unsigned long long want = ((G == 32) ? 0xffffffffull : (G == 16) ? 0xffffull : 0xffull) << (grp * G);
     return (m & want) != 0ull;
 }
 
@@ -383,13 +393,14 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
     // warm starts for the predict / update quadratures; part of the carry so that a chunked run is bit-identical
     double lamA = qnan, lamB = qnan;
     if (a.t_begin != 0 && a.c_lam) { lamA = a.c_lam[((size_t)b * 2) * G + l]; lamB = a.c_lam[((size_t)b * 2 + 1) * G + l]; }
-    double ywin = 0.0;                  // 16-step window of measurements, one per lane
+    double ywin = 0.0;                  // window of measurements (16 steps, or G when G < 16), one per lane
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
         // measurements: one coalesced 128-byte load per group every 16 steps, handed out by a lane shuffle
-        const int tw = (t - a.t_begin) & 15;
-        if (tw == 0) ywin = (t + (l & 15) < a.t_end) ? yrow[t + (l & 15)] : 0.0;
-        const double y = __shfl(ywin, tw, 16);
+        constexpr int YW = (G < 16) ? G : 16;
+        const int tw = (t - a.t_begin) & (YW - 1);
+        if (tw == 0) ywin = (t + (l & (YW - 1)) < a.t_end) ? yrow[t + (l & (YW - 1))] : 0.0;
+        const double y = __shfl(ywin, tw, YW);
         if (!dead) {
             int bad = 0;
 #pragma nounroll

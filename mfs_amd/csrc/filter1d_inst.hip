@@ -9,9 +9,9 @@
 namespace mfs {
 
 extern KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // defined in capi.hip
-extern Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][3];
+extern Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
-extern Cf1dLaunch g_cf[MFS_MAX_N + 1][3];
+extern Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 
 constexpr int kBlockLdsBudget = 64 * 1024;
 
@@ -89,7 +89,7 @@ hipError_t launch_cf_fast(const Cf1dArgs& a, int grid, int lds, hipStream_t s) {
 template <int N, int G>
 void reg_fast(int gi) {
     g_cf[N][gi] = &launch_cf_fast<N, G>;
-    KernelEntry& e = g_table[N][3 + gi];
+    KernelEntry& e = g_table[N][3 + gi];  // gi: 0..2 = G 16 / 32 / 64, 3 = G 8
     g_fast_filter[N][gi] = &launch_filter_fast<N, G>;
     e.filter = nullptr;
     e.quad = &launch_quad_fast<N, G>;
@@ -103,6 +103,7 @@ void reg_all() {
     if constexpr (N <= 16) reg<N, 16>(0);
     if constexpr (N <= 32) reg<N, 32>(1);
     reg<N, 64>(2);
+    if constexpr (N + 1 <= 8) reg_fast<N, 8>(3);
     if constexpr (N + 1 <= 16) reg_fast<N, 16>(0);
     if constexpr (N + 1 <= 32) reg_fast<N, 32>(1);
     reg_fast<N, 64>(2);

@@ -588,8 +588,9 @@ struct KernelEntry {
     int lanes_per_filter;
 };
 
-// registry slots per N: [0..2] dense path with G = 16 / 32 / 64, [3..5] fast path with G = 16 / 32 / 64
-constexpr int kSlots = 6;
+// registry slots per N: [0..2] dense path with G = 16 / 32 / 64, [3..5] fast path with G = 16 / 32 / 64,
+// [6] fast path with G = 8 (N <= 7: eight filters per wavefront)
+constexpr int kSlots = 7;
 using Filter1dFastLaunch = hipError_t (*)(const Filter1dArgs&, int grid, int lds_doubles_per_filter, hipStream_t);
 
 }  // namespace mfs

@@ -59,7 +59,7 @@ def test_chunked_graph_replay_is_bit_identical_to_single_launch():
     m, means, nell = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys)
     npt.assert_array_equal(m, whole[0])
     npt.assert_array_equal(nell, whole[2])
-    assert geo[0] == 16 and geo[2] == -(-B // geo[1])
+    assert geo[0] == 8 and geo[1] == 8 and geo[2] == -(-B // geo[1])   # N = 7: eight lanes per filter, eight filters per wave
     # NLL-only runs (no moment stream) agree too
     (nll_only, _), _ = _plan_run(N, T, B, 0, ys, ic, tables, lik, want_moments=False)
     npt.assert_array_equal(nll_only[2], whole[2])
