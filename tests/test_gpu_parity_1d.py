@@ -291,3 +291,36 @@ def test_fast_and_dense_device_paths_agree(N, monkeypatch):
         npt.assert_allclose(x1[0][i1], x2[0][i2], rtol=tol, atol=tol)
         big = w2[0][i2] > 1e-8
         npt.assert_allclose(w1[0][i1][big], w2[0][i2][big], rtol=max(tol, 1e-9) * 10)
+
+
+@pytest.mark.parametrize('N', [7, 8, 15, 16, 31, 32])
+def test_lane_group_boundaries_and_maximum_order(N):
+    """N = 7 | 8, 15 | 16, 31 | 32 straddle the 8 / 16 / 32 / 64 lanes-per-filter instantiations; N = 32 is MFS_MAX_N.
+    Scaled central moments of a Gaussian: the rule must be the Gauss-Hermite rule (nodes to a conditioning-dependent
+    tolerance) and a short OU filter must track the exact Kalman filter."""
+    cms = np.array([[o.central_moment_of_normal(1., p) for p in range(2 * N)]])
+    w, x = quadtures.moment_quadrature(cms, 0.25, 1.5)
+    gh_x, gh_w = np.polynomial.hermite_e.hermegauss(N)
+    gh_w = gh_w / math.sqrt(2 * math.pi)
+    assert np.all(np.isfinite(w)) and np.all(np.isfinite(x))
+    order = np.argsort(x[0])
+    tol = 1e-10 if N <= 8 else 1e-7 if N <= 16 else 1e-2
+    npt.assert_allclose(x[0][order], 0.25 + 1.5 * gh_x, rtol=tol, atol=tol)
+    npt.assert_allclose(w[0].sum(), 1., rtol=1e-12)
+    big = gh_w > 1e-6
+    npt.assert_allclose(w[0][order][big], gh_w[big], rtol=max(tol * 100, 1e-8))
+    # a short filter run at this order
+    mdl = om.ou_gaussian(N)
+    F, Sigma = mdl['F'], mdl['Sigma']
+    ys, _ = synth.ou_gaussian_batch(3, 40, seed=N)
+    from mfs_amd import stats
+    _, cc, _, cm, _ = moments.sde_cond_moments_normal(lambda xx: F * xx, lambda xx: Sigma)
+    cmss, means, nell = filtering.moment_filter_cms(cc, cm, lambda y, xx: stats.norm_pdf(y, xx, 1.), mdl['cms0'],
+                                                    mdl['mean0'], ys)
+    for b in range(3):
+        if not np.isfinite(nell[b]):  # N >= 25: a pivot may round below zero (see test_ou_convergence_config3)
+            assert N >= 25
+            continue
+        kf_m, kf_v, kf_nell = mdl['kf'](ys[b])
+        assert np.abs(means[b] - kf_m).max() < (2e-3 if N <= 8 else 1e-6)
+        npt.assert_allclose(nell[b], kf_nell, rtol=1e-4 if N <= 8 else 1e-8)
