@@ -99,9 +99,12 @@ def main():
     model, N, T, B, mode, transition = WORKLOADS[args.workload]
     B = args.B or B
     T = args.T or T
-    comm = dist.Communicator.from_env()  # TCP control plane (mfs_amd/rdzv.py) + RCCL communicator for the NLL gather
     L = _lib.lib()
-    _lib.check(L.mfs_set_device(local_rank))
+    # one GPU per rank; on a box with fewer GPUs than ranks (rehearsals only) ranks share devices and RCCL, which
+    # refuses duplicate GPUs, falls back to the reported host gather
+    device = local_rank % max(_lib.device_count(), 1)
+    comm = dist.Communicator.from_env(device=device)  # TCP control plane (mfs_amd/rdzv.py) + RCCL for the NLL gather
+    _lib.check(L.mfs_set_device(device))
 
     # ---- synthetic inputs for this rank's shard (seeded per rank), uploaded before the timed region
     rng = np.random.default_rng(1234 + rank)
@@ -126,7 +129,7 @@ def main():
 
     plan = C.c_void_p()
     _lib.check(L.mfs_plan_1d_create(C.byref(plan), C.byref(mstruct), _lib.MODE[mode], N, T, B, 0, args.chunk,
-                                    local_rank))
+                                    device))
     geo = [C.c_int() for _ in range(4)]
     _lib.check(L.mfs_plan_1d_geometry(plan, *[C.byref(g) for g in geo]))
     stream = C.c_void_p()
@@ -210,7 +213,7 @@ def main():
             'valu_fp64': {'achieved': tflops, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                           'frac': tflops / FP64_VALU_PEAK_TFLOPS, 'algorithmic_flops_per_filter_step': flops_step},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # contract: the CPU baseline is a rank-0, N = 1 measurement
             out['cpu_baseline'] = cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, nell, first_nan)
         print(json.dumps(out))
     comm.close()
@@ -236,7 +239,11 @@ def cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, dev_nell, 
     """The oracle's C port (OpenMP over replicates) timed on this box's host cores, on a bounded sample of the same
     workload.  The reference's own JAX-CPU path cannot run here (no JAX in the image): kind = "port"."""
     from oracle import c_oracle, tme_sympy, models as om
-    threads = c_oracle.max_threads()
+    # all host cores this process may run on, regardless of OMP_NUM_THREADS (torchrun exports OMP_NUM_THREADS=1)
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
     # independent SymPy derivation of the coefficient tables where it is cheap (shared-parameter models)
     if model == 'benes':
         odt, _, _, odrift, odisp, _, _ = om.benes_bernoulli(N)
@@ -256,7 +263,7 @@ def cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, dev_nell, 
         lp = lik.params[:nb] if lik.params.ndim == 2 else lik.params
         t0 = time.perf_counter()
         res = c_oracle.filter_1d(modei, N, ys[:nb], m0, ic.mean, np.sqrt(ic.variance), kind, umap, tables.n_terms,
-                                 cf, tables.mean_x_coef, lik_kind, lp, want_moments=False)
+                                 cf, tables.mean_x_coef, lik_kind, lp, want_moments=False, nthreads=threads)
         return time.perf_counter() - t0, res
 
     nb = min(ys.shape[0], 4 * threads)

@@ -36,9 +36,10 @@ class Communicator:
         self._rdzv = None
         self._comm = None
         self.rccl_error = None
+        self.device = local_rank
 
     @classmethod
-    def from_env(cls, backend=None, control=None, data=None):
+    def from_env(cls, backend=None, control=None, data=None, device=None):
         """`backend='gloo'` is shorthand for control='gloo', data='host' (the CPU test configuration)."""
         if backend == 'gloo':
             control, data = 'gloo', 'host'
@@ -46,6 +47,7 @@ class Communicator:
         world = int(os.environ.get('WORLD_SIZE', '1'))
         local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self = cls(rank, world, local_rank, control or 'tcp', data or 'rccl')
+        self.device = local_rank if device is None else device
         if world > 1:
             if self.control == 'gloo':
                 import torch.distributed as td
@@ -89,7 +91,7 @@ class Communicator:
         uid = self._allgather_obj(bytes(idbuf))[0]
         idbuf = (C.c_char * 128).from_buffer_copy(uid)
         comm = C.c_void_p()
-        _lib.check(L.mfs_comm_init(C.byref(comm), C.cast(idbuf, C.c_void_p), self.world, self.rank, self.local_rank))
+        _lib.check(L.mfs_comm_init(C.byref(comm), C.cast(idbuf, C.c_void_p), self.world, self.rank, self.device))
         self._comm = comm
 
     # -- control plane (host)
