@@ -178,13 +178,20 @@ int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean
 
 /*
  * ---- N-D moment filter (d = 2), host pointers ------------------------------------------------------------------
- * Replaces moment_filter_nd_rms / moment_filter_nd_cms (mfs/multi_dims/filtering.py:283-344, 210-280) with the
- * TME transition of mfs/multi_dims/moments.py:414-479 ('multi-index' signature) for B replicates.  The scaled mode
- * (:33-207) is not on the device: no reference driver uses it (dardel/prey_predator/mf.py:70 raises for it).
+ * Replaces moment_filter_nd_rms / moment_filter_nd_cms (mfs/multi_dims/filtering.py:283-344, 210-280) for B
+ * replicates, with either transition family the reference offers.  The scaled mode (:33-207) is not on the device: no
+ * reference driver uses it (dardel/prey_predator/mf.py:70 raises for it).
  *
- * Model: polynomial drift / dispersion reduced on the host to the operator table Q_kappa(x), 1 <= |kappa| <= 4
+ * MFS_ND_TRANS_OPERATOR ('multi-index' signature, sde_cond_moments_tme, mfs/multi_dims/moments.py:414-479):
+ * polynomial drift / dispersion reduced on the host to the operator table Q_kappa(x), 1 <= |kappa| <= 4
  * (TME order <= 2), dense per-variable extent D: coef [MFS_ND_TERMS][D][D] in graded-lex kappa order
  * (0,1),(1,0),(0,2),(1,1),(2,0),(0,3),...,(4,0), zeros where the model has no term.  Conditional mean_k = x_k + Q_{e_k}.
+ *
+ * MFS_ND_TRANS_GAUSSIAN ('index' signature, the Normal closures sde_cond_moments_tme_normal / _euler_maruyama,
+ * mfs/multi_dims/moments.py:340-411, 257-337, whose moments the reference takes from Kan's formula, :110-154):
+ * X' | x ~ N(mu(x), S(x)); rows 0..4 of coef hold the polynomials mu_0, mu_1, S_00, S_01, S_11 (n_terms = 5), the
+ * other rows are ignored.  The kernel evaluates E[(X'_0-c_0)^a (X'_1-c_1)^b] by the Stein recursion, which is the
+ * same polynomial in (mu - c, S) as Kan's sum.
  * The likelihood looks at one state component (mfs/multi_dims/ss_models.py:63-67).
  *
  *   N              quadrature order per dimension: s = N(N+1)/2 Gram size, z = N(2N+1) moments (|n| <= 2N-1), 2..7
@@ -196,13 +203,17 @@ int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean
  */
 #define MFS_ND_TERMS 14
 #define MFS_ND_MAX_EXTENT 6
+#define MFS_ND_TRANS_OPERATOR 0
+#define MFS_ND_TRANS_GAUSSIAN 1
 typedef struct mfs_model_nd {
     int32_t d;             /* 2 */
+    int32_t trans_kind;    /* MFS_ND_TRANS_* */
     int32_t n_terms;       /* MFS_ND_TERMS rows are always passed; terms >= n_terms are known to be zero */
     int32_t extent;        /* D <= MFS_ND_MAX_EXTENT */
     int32_t lik_kind;      /* MFS_LIK_* */
     int32_t n_lik;
     int32_t lik_component; /* which state component the likelihood reads */
+    int32_t reserved;      /* 0 */
     const double* coef;    /* [MFS_ND_TERMS][D][D] */
     const double* lik;     /* [n_lik] */
 } mfs_model_nd;

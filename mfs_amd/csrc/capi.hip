@@ -19,7 +19,7 @@ Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch; int S, Z, lds_bytes; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss; int S, Z, lds_bytes; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
 }
 
@@ -507,6 +507,11 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     if (N < 2 || N > 7) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, 7] for d = 2", N);
     const mfs::NdEntry& ke = mfs::g_nd_table[N];
     if (!ke.launch) return fail(MFS_EUNSUPPORTED, "no N-D kernel compiled for N = %d", N);
+    if (model->trans_kind != MFS_ND_TRANS_OPERATOR && model->trans_kind != MFS_ND_TRANS_GAUSSIAN)
+        return fail(MFS_EINVAL, "unknown N-D transition kind %d", model->trans_kind);
+    if (model->trans_kind == MFS_ND_TRANS_GAUSSIAN && model->n_terms != 5)
+        return fail(MFS_EINVAL, "the Gaussian N-D transition carries 5 polynomials (mu_0, mu_1, S_00, S_01, S_11)");
+    if (model->n_terms < 0 || model->n_terms > MFS_ND_TERMS) return fail(MFS_EINVAL, "bad n_terms %d", model->n_terms);
     if (z != ke.Z) return fail(MFS_EINVAL, "The size of multi_indices %d must match that of the moments %d.", z, ke.Z);
     if (model->extent < 1 || model->extent > MFS_ND_MAX_EXTENT)
         return fail(MFS_EUNSUPPORTED, "coefficient extent %d outside [1, %d]", model->extent, MFS_ND_MAX_EXTENT);
@@ -568,7 +573,7 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
         }
         a.coef = d_coef; a.lik = d_lik; a.inds = d_inds; a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0;
         a.ys = d_ys; a.out_mom = d_mom; a.out_mean = d_means; a.out_nell = d_nell; a.out_first_nan = d_fn;
-        e = ke.launch(a, B, s);
+        e = (model->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : ke.launch)(a, B, s);
     }
     d2h(out_moments, d_mom, (size_t)B * T * Z * 8);
     d2h(out_means, d_means, (size_t)B * T * 2 * 8);

@@ -1,29 +1,30 @@
-// filternd_inst.hip -- instantiates the d = 2 N-D kernels for quadrature orders 2..7 and registers their launchers.
+// filternd_inst.hip -- instantiates the d = 2 N-D kernels for quadrature orders 2..7, both transition families
+// (TK = 0 operator table, TK = 1 Normal closure), and registers their launchers.
 #include "filternd_kernel.hpp"
 
 namespace mfs {
 
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch; int S, Z, lds_bytes; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss; int S, Z, lds_bytes; };
 NdEntry g_nd_table[8];
 
-template <int N>
+template <int N, int TK>
 hipError_t launch_nd(const FilterNdArgs& a, int grid, hipStream_t s) {
     constexpr int lds = NdTile<N>::kDoubles * 8;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, TK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((filternd_kernel<N>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
 template <int N>
 void reg_nd() {
-    g_nd_table[N] = NdEntry{&launch_nd<N>, NdTile<N>::S, NdTile<N>::Z, NdTile<N>::kDoubles * 8};
+    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, NdTile<N>::S, NdTile<N>::Z, NdTile<N>::kDoubles * 8};
     if constexpr (N < 7) reg_nd<N + 1>();
 }
 

@@ -445,7 +445,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     return poisoned;
 }
 
-template <int N>
+// TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
+template <int N, int TK>
 __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N>;
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R;
@@ -495,8 +496,13 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                     const double w = W[e];
                     const double x0 = lam[i0] + qm0, x1 = lam[NP + i1] + qm1;
                     if (half == 0) {
-                        s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
-                        s1 = fma(w, x1 + poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s1);  // kappa = (0, 1)
+                        if constexpr (TK == 0) {
+                            s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
+                            s1 = fma(w, x1 + poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s1);  // kappa = (0, 1)
+                        } else {
+                            s0 = fma(w, poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s0);       // mu_0(x)
+                            s1 = fma(w, poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s1);       // mu_1(x)
+                        }
                     } else {
                         const double wl = w * likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
                         s0 = fma(wl, x0, s0); s1 = fma(wl, x1, s1); s4 += wl;
@@ -523,6 +529,72 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 // ---- pass 2: every moment about the new centre.  Each thread owns up to two nodes per sweep of the
                 //      node list; for each moment (compile-time multi-index) the two contributions are added and
                 //      reduced across the wave at once, so no per-thread accumulator array exists (it would spill).
+                if (TK == 1 && half == 0) {
+                    // Normal closure: per node, E[(X'_0-c_0)^a (X'_1-c_1)^b] for a + b <= 2N-1 by the Stein recursion
+                    //   M(0,b) = m_1 M(0,b-1) + (b-1) S_11 M(0,b-2)
+                    //   M(a,b) = m_0 M(a-1,b) + (a-1) S_00 M(a-2,b) + b S_01 M(a-1,b-1)
+                    // (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), mfs/multi_dims/moments.py:110-154), three
+                    // rows of the table live at a time; every entry goes straight into the wave reduction.
+                    for (int base = 0; base < R; base += 512) {
+                        double wA, wB, mA0, mA1, sA00, sA01, sA11, mB0, mB1, sB00, sB01, sB11;
+                        {
+                            const int eA = base + tid, eB = base + 256 + tid;
+                            const bool okA = eA < R, okB = eB < R;
+                            const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
+                            const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
+                            wA = okA ? W[eA] : 0.0;
+                            wB = okB ? W[eB] : 0.0;
+                            const double xA0 = lam[iA0] + qm0, xA1 = lam[NP + iA1] + qm1;
+                            const double xB0 = lam[iB0] + qm0, xB1 = lam[NP + iB1] + qm1;
+                            mA0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xA0, xA1) - c0;
+                            mA1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xA0, xA1) - c1;
+                            sA00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xA0, xA1);
+                            sA01 = poly2d(coef + 3 * DD, a.D, a.ext[3], xA0, xA1);
+                            sA11 = poly2d(coef + 4 * DD, a.D, a.ext[4], xA0, xA1);
+                            mB0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xB0, xB1) - c0;
+                            mB1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xB0, xB1) - c1;
+                            sB00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xB0, xB1);
+                            sB01 = poly2d(coef + 3 * DD, a.D, a.ext[3], xB0, xB1);
+                            sB11 = poly2d(coef + 4 * DD, a.D, a.ext[4], xB0, xB1);
+                        }
+                        double MA[3][P], MB[3][P];
+#pragma unroll
+                        for (int n0 = 0; n0 < P; ++n0) {
+                            const int r = n0 % 3, r1 = (n0 + 2) % 3, r2 = (n0 + 1) % 3;   // rows n0, n0-1, n0-2
+#pragma unroll
+                            for (int n1 = 0; n1 < P - n0; ++n1) {
+                                double vA, vB;
+                                if (n0 == 0) {
+                                    if (n1 == 0) { vA = 1.0; vB = 1.0; }
+                                    else {
+                                        vA = mA1 * MA[0][n1 - 1]; vB = mB1 * MB[0][n1 - 1];
+                                        if (n1 >= 2) {
+                                            vA = fma((double)(n1 - 1) * sA11, MA[0][n1 - 2], vA);
+                                            vB = fma((double)(n1 - 1) * sB11, MB[0][n1 - 2], vB);
+                                        }
+                                    }
+                                } else {
+                                    vA = mA0 * MA[r1][n1]; vB = mB0 * MB[r1][n1];
+                                    if (n0 >= 2) {
+                                        vA = fma((double)(n0 - 1) * sA00, MA[r2][n1], vA);
+                                        vB = fma((double)(n0 - 1) * sB00, MB[r2][n1], vB);
+                                    }
+                                    if (n1 >= 1) {
+                                        vA = fma((double)n1 * sA01, MA[r1][n1 - 1], vA);
+                                        vB = fma((double)n1 * sB01, MB[r1][n1 - 1], vB);
+                                    }
+                                }
+                                MA[r][n1] = vA; MB[r][n1] = vB;
+                                const int sdeg = n0 + n1, zi = sdeg * (sdeg + 1) / 2 + n0;
+                                const double v = wave_sum64(fma(wA, vA, wB * vB));
+                                if ((tid & 63) == 0) {
+                                    double* slot = red + (tid >> 6) * (Z + 4) + zi;
+                                    *slot = (base == 0) ? v : *slot + v;
+                                }
+                            }
+                        }
+                    }
+                } else
                 for (int base = 0; base < R; base += 512) {
                     double wA, wB, pxA0[P], pxA1[P], pxB0[P], pxB1[P], QA[kNdTerms], QB[kNdTerms];
                     {
@@ -540,7 +612,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                             pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1);
                             pxB0[p] = pxB0[p - 1] * (xB0 - c0); pxB1[p] = pxB1[p - 1] * (xB1 - c1);
                         }
-                        if (half == 0) {
+                        if (TK == 0 && half == 0) {
 #pragma unroll
                             for (int k = 0; k < kNdTerms; ++k) {
                                 QA[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xA0, xA1) : 0.0;
@@ -559,7 +631,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                         for (int n0 = 0; n0 <= s; ++n0) {
                             const int n1 = s - n0, zi = s * (s + 1) / 2 + n0;
                             double vA = pxA0[n0] * pxA1[n1], vB = pxB0[n0] * pxB1[n1];
-                            if (half == 0) {
+                            if (TK == 0 && half == 0) {
 #pragma unroll
                                 for (int k = 0; k < kNdTerms; ++k) {
                                     if (kKap0[k] <= n0 && kKap1[k] <= n1) {

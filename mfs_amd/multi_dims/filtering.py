@@ -1,7 +1,7 @@
 """The N-D moment filters on MI355X, mirroring `mfs.multi_dims.filtering`.
 
 Same names, positional order and return tuples as the reference (mfs/multi_dims/filtering.py:283-288, 210-217,
-33-41).  d = 2 runs on `filternd_kernel` (mfs_amd/csrc/filternd_kernel.hpp); d = 1 is routed to the 1-D kernels (the
+33-41); both closure signatures ('multi-index' for sde_cond_moments_tme, 'index' for the Normal closures, :245-249).  d = 2 runs on `filternd_kernel` (mfs_amd/csrc/filternd_kernel.hpp); d = 1 is routed to the 1-D kernels (the
 reference guarantees the d = 1 N-D path equals the 1-D path, tests/test_filtering.py:304-329).  `ys` may carry a leading
 replicate axis (B, T).  No CPU fallback.
 """
@@ -13,7 +13,7 @@ import numpy as np
 from mfs_amd import _lib, sym
 from mfs_amd.multi_dims.moments import TransitionRefND
 from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices
-from mfs_amd.tme_poly_nd import TransitionTablesND
+from mfs_amd.tme_poly_nd import GaussianTablesND, TransitionTablesND
 
 __all__ = ['moment_filter_nd_rms', 'moment_filter_nd_cms', 'moment_filter_nd_scms']
 
@@ -27,23 +27,34 @@ class _Forbidden:
     __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __pow__ = __neg__ = _no
 
 
-def _trace_transition(fn_and_flag, mode):
+def _trace_transition(fn_and_flag, mode, moments_partial_order=None):
     fn, signature = fn_and_flag
-    if signature != 'multi-index':
-        raise sym.NotDeviceDescribable("the device N-D path implements the 'multi-index' signature "
-                                       '(sde_cond_moments_tme); the Kan-formula Normal closures use it too upstream '
-                                       'only through index lookups and are not on the device yet')
+    if signature not in ('multi-index', 'index'):
+        raise sym.NotDeviceDescribable(f"unknown transition-moment signature {signature!r}")
+    second = sym.ORDER
     if mode == 'raw':
-        ref = fn(sym.X, sym.ORDER)
+        ref = fn(sym.X, second)
         ok = isinstance(ref, TransitionRefND) and ref.mean is None
     else:
-        ref = fn(sym.X, sym.ORDER, sym.MEAN)
+        ref = fn(sym.X, second, sym.MEAN)
         ok = isinstance(ref, TransitionRefND) and ref.mean is sym.MEAN
     if not isinstance(ref, TransitionRefND):
         raise sym.NotDeviceDescribable('the transition-moment callable is not device-describable; build it with '
-                                       'mfs_amd.multi_dims.moments.sde_cond_moments_tme')
+                                       'mfs_amd.multi_dims.moments.sde_cond_moments_tme / _tme_normal / '
+                                       '_euler_maruyama')
     if not ok:
         raise sym.NotDeviceDescribable('the transition-moment callable does not forward its mean argument')
+    gaussian = isinstance(ref.tables, GaussianTablesND)
+    if gaussian != (signature == 'index'):
+        raise sym.NotDeviceDescribable(f"signature {signature!r} does not match the closure: the Normal closures take "
+                                       "'index', sde_cond_moments_tme takes 'multi-index' "
+                                       '(mfs/multi_dims/filtering.py:245-249)')
+    if gaussian and moments_partial_order is not None:
+        # an 'index' closure looks moments up in the table it was built for (mfs/multi_dims/moments.py:293-300)
+        built_for = np.asarray(fn.multi_indices)
+        if built_for.shape != np.asarray(moments_partial_order[0]).shape or \
+                np.any(built_for != np.asarray(moments_partial_order[0])):
+            raise ValueError("the 'index' closure was built for a different multi-index table than the filter's")
     return ref.tables
 
 
@@ -62,26 +73,32 @@ def _trace_likelihood(fn, d):
     raise sym.NotDeviceDescribable(f'measurement_cond_pdf is not device-describable: {last}')
 
 
-def _model_struct(tables: TransitionTablesND, lik: sym.LikelihoodSpec):
+def _model_struct(tables, lik: sym.LikelihoodSpec):
     if tables.d != 2:
         raise sym.NotDeviceDescribable('the device N-D path supports d = 2')
     dense, D = tables.dense_table()
     if D > _lib.ND_MAX_EXTENT:
         raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds MFS_ND_MAX_EXTENT = {_lib.ND_MAX_EXTENT}')
     coef = np.zeros((_lib.ND_TERMS, D, D))
-    last = 0
-    for t, kap in enumerate(tables.kappas):
-        kap = tuple(int(v) for v in kap)
-        if kap not in _lib.ND_KAPPAS:
-            raise sym.NotDeviceDescribable(f'derivative term {kap} needs |kappa| <= 4, i.e. tme_order <= 2 on the device')
-        row = _lib.ND_KAPPAS.index(kap)
-        coef[row] = dense[t]
-        last = max(last, row + 1)
+    if isinstance(tables, GaussianTablesND):
+        coef[:5] = dense        # mu_0, mu_1, S_00, S_01, S_11
+        kind, last = _lib.ND_TRANS_GAUSSIAN, 5
+    else:
+        kind, last = _lib.ND_TRANS_OPERATOR, 0
+        for t, kap in enumerate(tables.kappas):
+            kap = tuple(int(v) for v in kap)
+            if kap not in _lib.ND_KAPPAS:
+                raise sym.NotDeviceDescribable(f'derivative term {kap} needs |kappa| <= 4, i.e. tme_order <= 2 on the '
+                                               'device')
+            row = _lib.ND_KAPPAS.index(kap)
+            coef[row] = dense[t]
+            last = max(last, row + 1)
     lp = np.ascontiguousarray(lik.params, dtype=np.float64)
     if lp.ndim != 1:
         raise sym.NotDeviceDescribable('per-replicate likelihood parameters are not supported on the N-D path yet')
     m = _lib.MfsModelNd()
     m.d, m.n_terms, m.extent = 2, last, D
+    m.trans_kind = kind
     m.lik_kind, m.n_lik, m.lik_component = _lib.LIK[lik.kind], lp.shape[0], lik.component
     m.coef = coef.ctypes.data_as(_lib.c_double_p)
     m.lik = lp.ctypes.data_as(_lib.c_double_p)
@@ -132,7 +149,7 @@ def moment_filter_nd_rms(state_cond_raw_moments: Tuple[Callable, str], measureme
                          moments_partial_order, rms0, stable: bool = False, *, device: int = 0,
                          return_first_nan: bool = False):
     """Filtering with raw moments (mfs/multi_dims/filtering.py:283-344): returns (rmss (T, z), nell)."""
-    tables = _trace_transition(state_cond_raw_moments, 'raw')
+    tables = _trace_transition(state_cond_raw_moments, 'raw', moments_partial_order)
     lik = _trace_likelihood(measurement_cond_pdf, tables.d)
     m, _, nell, fn = _run_nd('raw', tables, lik, ys, moments_partial_order, rms0, None, stable, device)
     return (m, nell, fn) if return_first_nan else (m, nell)
@@ -142,10 +159,10 @@ def moment_filter_nd_cms(state_cond_central_moments: Tuple[Callable, str], state
                          measurement_cond_pdf: Callable, ys, moments_partial_order, cms0, mean0,
                          stable: bool = False, *, device: int = 0, return_first_nan: bool = False):
     """Filtering with central moments (mfs/multi_dims/filtering.py:210-280): returns (cmss, means (T, d), nell)."""
-    tables = _trace_transition(state_cond_central_moments, 'central')
+    tables = _trace_transition(state_cond_central_moments, 'central', moments_partial_order)
     ref = state_cond_mean(sym.X)
     if not (isinstance(ref, TransitionRefND) and ref.tables is tables):
-        raise sym.NotDeviceDescribable('state_cond_mean must come from the same sde_cond_moments_tme call as the '
+        raise sym.NotDeviceDescribable('state_cond_mean must come from the same sde_cond_moments_* call as the '
                                        'conditional central moments')
     lik = _trace_likelihood(measurement_cond_pdf, tables.d)
     m, means, nell, fn = _run_nd('central', tables, lik, ys, moments_partial_order, cms0, mean0, stable, device)

@@ -8,9 +8,10 @@ from scipy.special import comb as _comb, factorial as _factorial
 
 from mfs_amd import sym
 from mfs_amd.multi_dims.multi_indices import find_indices
-from mfs_amd.tme_poly_nd import TransitionTablesND, tme_tables_nd
+from mfs_amd.tme_poly_nd import TransitionTablesND, GaussianTablesND, tme_tables_nd, normal_tables_nd
 
-__all__ = ['raw_moments_mvn_kan', 'central_moments_mvn_kan', 'sde_cond_moments_tme', 'extract_moments',
+__all__ = ['raw_moments_mvn_kan', 'central_moments_mvn_kan', 'sde_cond_moments_tme', 'sde_cond_moments_tme_normal',
+           'sde_cond_moments_euler_maruyama', 'extract_moments',
            'extract_mean', 'extract_cov', 'marginalise_moments']
 
 
@@ -96,3 +97,33 @@ def sde_cond_moments_tme(drift: Callable, dispersion: Callable, dt: float, tme_o
     tables = tme_tables_nd(drift, dispersion, d, float(dt), int(tme_order))
     return (_CondMomentsND(tables, 'raw'), _CondMomentsND(tables, 'central'), _CondMomentsND(tables, 'scaled'),
             _CondMeanND(tables), _CondMeanND(tables, with_var=True))
+
+
+class _CondMomentsNDIndexed:
+    """'index' signature of the Normal-closure factories: the second argument selects rows of the moment table the
+    factory was built for (mfs/multi_dims/moments.py:293-300: `rms[index]`)."""
+
+    def __init__(self, tables, which, multi_indices):
+        self.tables, self.which, self.multi_indices = tables, which, np.asarray(multi_indices)
+
+    def __call__(self, x, index, mean=None, scale=None):
+        if x is sym.X or sym.is_symbolic(x):
+            return TransitionRefND(self.tables, self.which, mean, scale)
+        return self.tables.cond_moments(x, self.multi_indices[np.asarray(index, dtype=int)], mean, scale)
+
+
+def _indexed_five(tables, multi_indices):
+    return (_CondMomentsNDIndexed(tables, 'raw', multi_indices), _CondMomentsNDIndexed(tables, 'central', multi_indices),
+            _CondMomentsNDIndexed(tables, 'scaled', multi_indices), _CondMeanND(tables), _CondMeanND(tables, with_var=True))
+
+
+def sde_cond_moments_tme_normal(drift: Callable, dispersion: Callable, dt: float, tme_order: int, multi_indices):
+    """Normal closure with TME mean / covariance (mfs/multi_dims/moments.py:340-411); 'index' signature."""
+    mi = np.asarray(multi_indices)
+    return _indexed_five(normal_tables_nd(drift, dispersion, mi.shape[-1], float(dt), int(tme_order)), mi)
+
+
+def sde_cond_moments_euler_maruyama(drift: Callable, dispersion: Callable, dt: float, multi_indices):
+    """Euler--Maruyama Normal closure (mfs/multi_dims/moments.py:257-337); 'index' signature."""
+    mi = np.asarray(multi_indices)
+    return _indexed_five(normal_tables_nd(drift, dispersion, mi.shape[-1], float(dt), 'euler'), mi)

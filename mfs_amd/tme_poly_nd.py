@@ -267,3 +267,101 @@ def tme_tables_nd(drift, dispersion, d: int, dt: float, order: int) -> Transitio
             acc = acc + (dt ** r / math.factorial(r)) * term
         var.append(acc.trimmed())
     return TransitionTablesND(d, kappas, Q, var, f'tme_{order}')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Normal closures (mfs/multi_dims/moments.py:257-337 Euler--Maruyama, :340-411 TME mean / covariance)
+# ---------------------------------------------------------------------------------------------------------------------
+class GaussianTablesND:
+    """X' | x ~ N(mu(x), Sigma(x)) with polynomial mean vector and covariance matrix (d = 2 on the device).
+
+    The reference evaluates E[prod (X'_k - c_k)^{n_k}] with Kan's formula per multi-index
+    (mfs/multi_dims/moments.py:110-154); for d = 2 the same numbers follow from Stein's lemma as a two-term recursion,
+        M(a, b) = m_0 M(a-1, b) + (a-1) S_00 M(a-2, b) + b S_01 M(a-1, b-1),     M(0, b) = m_1 M(0, b-1) + (b-1) S_11 M(0, b-2),
+    with m = mu(x) - c, which is what the kernel runs per node.
+    """
+
+    def __init__(self, d, mean, cov, label):
+        self.d, self.mean, self.cov, self.label = d, mean, cov, label
+
+    def dense_table(self):
+        """(5, D, D): mu_0, mu_1, S_00, S_01, S_11."""
+        if self.d != 2:
+            raise NotDeviceDescribable('the device N-D path supports d = 2')
+        polys = [self.mean[0], self.mean[1], self.cov[0][0], self.cov[0][1], self.cov[1][1]]
+        D = max(max(p.coef.shape) for p in polys)
+        out = np.zeros((5, D, D))
+        for t, p in enumerate(polys):
+            out[(t,) + tuple(slice(0, n) for n in p.coef.shape)] = p.coef
+        return np.ascontiguousarray(out), D
+
+    def cond_mean(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.stack([m(x) for m in self.mean], axis=-1)
+
+    def cond_var(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.stack([self.cov[i][i](x) for i in range(self.d)], axis=-1)
+
+    def cond_moments(self, x, multi_indices, mean=None, scale=None):
+        if self.d != 2:
+            raise NotImplementedError
+        x = np.asarray(x, dtype=np.float64)
+        mi = np.asarray(multi_indices, dtype=int)
+        c = np.zeros(2) if mean is None else np.broadcast_to(np.asarray(mean, dtype=np.float64), (2,))
+        m0, m1 = self.mean[0](x) - c[0], self.mean[1](x) - c[1]
+        s00, s01, s11 = self.cov[0][0](x), self.cov[0][1](x), self.cov[1][1](x)
+        P = int(mi.max()) + 1
+        M = {}
+        for b in range(P):
+            M[0, b] = np.ones_like(m0) if b == 0 else m1 * M[0, b - 1] + ((b - 1) * s11 * M[0, b - 2] if b >= 2 else 0.)
+        for a in range(1, P):
+            for b in range(P):
+                v = m0 * M[a - 1, b]
+                if a >= 2:
+                    v = v + (a - 1) * s00 * M[a - 2, b]
+                if b >= 1:
+                    v = v + b * s01 * M[a - 1, b - 1]
+                M[a, b] = v
+        out = np.stack([M[int(n0), int(n1)] for n0, n1 in mi], axis=-1)
+        if scale is not None:
+            out = out / np.prod(np.asarray(scale, dtype=np.float64) ** mi, axis=-1)
+        return out
+
+
+def normal_tables_nd(drift, dispersion, d: int, dt: float, order) -> GaussianTablesND:
+    """`order` = 'euler' (mean x + a dt, covariance b b^T dt) or an int TME order (tme.mean_and_cov, truncated in dt):
+        cov_ij = sum_{r=1}^{M} dt^r/r! [ (1 + delta_ij) q_{r, e_i + e_j} - sum_{s=1}^{r-1} C(r, s) q_{s, e_i} q_{r-s, e_j} ]."""
+    a, g = trace_sde_nd(drift, dispersion, d)
+    xs = [PolyND.variable(d, k) for k in range(d)]
+    zero = PolyND(np.float64(0.), d)
+    if order == 'euler':
+        mean = [(xs[k] + dt * a[k]).trimmed() for k in range(d)]
+        cov = [[(dt * g[i][j]).trimmed() for j in range(d)] for i in range(d)]
+        return GaussianTablesND(d, mean, cov, 'euler')
+    order = int(order)
+    q = generator_power_tables_nd(a, g, order)
+
+    def e(i):
+        return tuple(1 if m == i else 0 for m in range(d))
+
+    def e2(i, j):
+        return tuple((1 if m == i else 0) + (1 if m == j else 0) for m in range(d))
+
+    mean = []
+    for k in range(d):
+        acc = xs[k]
+        for r in range(1, order + 1):
+            acc = acc + (dt ** r / math.factorial(r)) * q[r].get(e(k), zero)
+        mean.append(acc.trimmed())
+    cov = [[None] * d for _ in range(d)]
+    for i in range(d):
+        for j in range(d):
+            acc = zero
+            for r in range(1, order + 1):
+                term = (2. if i == j else 1.) * q[r].get(e2(i, j), zero)
+                for s in range(1, r):
+                    term = term - math.comb(r, s) * (q[s].get(e(i), zero) * q[r - s].get(e(j), zero))
+                acc = acc + (dt ** r / math.factorial(r)) * term
+            cov[i][j] = acc.trimmed()
+    return GaussianTablesND(d, mean, cov, f'tme_normal_{order}')

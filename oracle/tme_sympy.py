@@ -259,3 +259,44 @@ def operator_tables_1d(drift: Callable, dispersion: Callable, dt: float, tme_ord
         for (j,), c in p.terms():
             out[i, j] = float(c)
     return out
+
+
+def sde_cond_moments_normal_nd(drift: Callable, dispersion: Callable, d: int, dt: float, order, multi_indices):
+    """Normal closures of mfs/multi_dims/moments.py:257-337 (order='euler') and :340-411 (TME order): for every node,
+    raw_moments_mvn_kan(cond_mean - mean, cond_cov, multi_index).  'index' signature: (x, index[, mean])."""
+    from oracle.multi_dims import raw_moments_mvn_kan
+    xs = sp.symbols(f'x0:{d}', real=True)
+    a = [sp.sympify(e) for e in drift(list(xs))]
+    b = sp.Matrix(dispersion(list(xs)))
+    gam = b * b.T
+    if order == 'euler':
+        mean_e = [xs[k] + a[k] * sp.Float(dt) for k in range(d)]
+        cov_e = gam * sp.Float(dt)
+    else:
+        mean_e, cov_e = mean_and_cov_expr(xs, a, gam, dt, int(order))
+    mean_f = [_lambdify(tuple(xs), e) for e in mean_e]
+    cov_f = [[_lambdify(tuple(xs), cov_e[i, j]) for j in range(d)] for i in range(d)]
+    mi = np.asarray(multi_indices)
+
+    def _mc(x):
+        cols = [x[..., k] for k in range(d)]
+        m = np.stack([f(*cols) for f in mean_f], axis=-1)
+        c = np.stack([np.stack([cov_f[i][j](*cols) for j in range(d)], axis=-1) for i in range(d)], axis=-2)
+        return m, c
+
+    def cond_cms(x, index, mean):
+        x = np.asarray(x, dtype=np.float64)
+        m, c = _mc(x)
+        mean = np.broadcast_to(np.asarray(mean, dtype=np.float64), (d,))
+        flat_m, flat_c = m.reshape(-1, d), c.reshape(-1, d, d)
+        out = np.array([[raw_moments_mvn_kan(fm - mean, fc, mi[int(i)]) for i in np.asarray(index)]
+                        for fm, fc in zip(flat_m, flat_c)])
+        return out.reshape(x.shape[:-1] + (len(index),))
+
+    def cond_rms(x, index):
+        return cond_cms(x, index, np.zeros(d))
+
+    def cond_mean(x):
+        return _mc(np.asarray(x, dtype=np.float64))[0]
+
+    return cond_rms, cond_cms, cond_mean

@@ -89,3 +89,33 @@ def test_nd_shapes_errors_and_single_trajectory():
                                                         np.tile(gs.mean, (2, 1)), return_first_nan=True)
     assert fn[0] == 0 and np.isnan(nell[0]) and np.all(np.isnan(m[0]))
     assert fn[1] == -1 and nell[1] == nellB[1]
+
+
+@pytest.mark.parametrize('N,T,order', [(2, 60, 2), (3, 40, 2), (3, 40, 'euler'), (4, 25, 3), (5, 10, 2)])
+def test_prey_predator_normal_closures(N, T, order):
+    """'index'-signature Normal closures (mfs/multi_dims/moments.py:257-411; used by dardel/prey_predator/mf.py with
+    --trans=tme_normal_2 / euler; reference tests/test_filtering.py:182-222) against the oracle's Kan-formula path."""
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    _, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    if order == 'euler':
+        fns = moments.sde_cond_moments_euler_maruyama(drift, disp, dt, mi)
+    else:
+        fns = moments.sde_cond_moments_tme_normal(drift, disp, dt, order, mi)
+    orms, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(odrift, odisp, 2, dt, order, mi)
+    B = 2
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=10 + N)
+    cmss, means, nell = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
+    rc = omd.moment_filter_nd_cms((ocms, 'index'), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
+    npt.assert_allclose(nell[0], rc[2], rtol=1e-6)
+    npt.assert_allclose(means[0], rc[1], rtol=1e-6)
+    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
+    if N <= 3:
+        rmss, nell_r = filtering.moment_filter_nd_rms((fns[0], 'index'), pmf, ys, (mi, inds), gs.rms)
+        rr = omd.moment_filter_nd_rms((orms, 'index'), opmf, ys[0], (mi, inds), ogs.rms)
+        npt.assert_allclose(nell_r[0], rr[1], rtol=1e-6)
+        npt.assert_allclose(rmss[0], rr[0], rtol=1e-6)
+    # a closure declared with the wrong signature, or built for another table, is refused
+    with pytest.raises(sym.NotDeviceDescribable):
+        filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)

@@ -85,3 +85,32 @@ def test_kan_and_extractors():
                            np.array([0.5, 0.5]), mi)
     npt.assert_allclose(gs.mean, [1., 1.])
     npt.assert_allclose(gs.cov, 1.5e-3 * np.eye(2))
+
+
+@pytest.mark.parametrize('order', [1, 2, 3, 'euler'])
+def test_nd_normal_closure_tables_match_kan_oracle(order):
+    """mean / covariance polynomials + Stein recursion == tme.mean_and_cov + Kan's formula
+    (mfs/multi_dims/moments.py:257-411, :110-154)."""
+    mi = mid.generate_graded_lexico_multi_indices(2, 5)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    _, _, ogs, odrift, odisp, _, _ = omd.prey_predator(mi)
+    fns = (moments.sde_cond_moments_euler_maruyama(drift, disp, dt, mi) if order == 'euler'
+           else moments.sde_cond_moments_tme_normal(drift, disp, dt, order, mi))
+    orms, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(odrift, odisp, 2, dt, order, mi)
+    x = np.array([[1.0, 1.1], [0.9, 1.2], [1.3, 0.7]])
+    idx = np.arange(mi.shape[0])
+    c = np.array([1.01, 0.98])
+    npt.assert_allclose(fns[1](x, idx, c), ocms(x, idx, c), rtol=1e-11, atol=1e-300)
+    npt.assert_allclose(fns[0](x, idx[3:7]), orms(x, idx[3:7]), rtol=1e-11)
+    npt.assert_allclose(fns[3](x), omean(x), rtol=1e-14)
+    dense, D = fns[1].tables.dense_table()
+    assert dense.shape == (5, D, D)
+    # traced: an 'index' closure describes itself and is tied to its table
+    tables = filtering._trace_transition((fns[1], 'index'), 'central', (mi, None))
+    assert tables is fns[1].tables
+    with pytest.raises(sym.NotDeviceDescribable):
+        filtering._trace_transition((fns[1], 'multi-index'), 'central', (mi, None))
+    with pytest.raises(ValueError):
+        filtering._trace_transition((fns[1], 'index'), 'central', (mi[:-1], None))
+    m, keep = filtering._model_struct(tables, filtering._trace_likelihood(pmf, 2))
+    assert m.trans_kind == 1 and m.n_terms == 5
