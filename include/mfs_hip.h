@@ -178,14 +178,15 @@ int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean
 
 /*
  * ---- N-D moment filter (d = 2), host pointers ------------------------------------------------------------------
- * Replaces moment_filter_nd_rms / moment_filter_nd_cms (mfs/multi_dims/filtering.py:283-344, 210-280) for B
- * replicates, with either transition family the reference offers.  The scaled mode (:33-207) is not on the device: no
- * reference driver uses it (dardel/prey_predator/mf.py:70 raises for it).
+ * Replaces moment_filter_nd_rms / moment_filter_nd_cms / moment_filter_nd_scms (mfs/multi_dims/filtering.py:283-344,
+ * 210-280, 33-207) for B replicates, with either transition family the reference offers.
  *
  * MFS_ND_TRANS_OPERATOR ('multi-index' signature, sde_cond_moments_tme, mfs/multi_dims/moments.py:414-479):
  * polynomial drift / dispersion reduced on the host to the operator table Q_kappa(x), 1 <= |kappa| <= 4
  * (TME order <= 2), dense per-variable extent D: coef [MFS_ND_TERMS][D][D] in graded-lex kappa order
  * (0,1),(1,0),(0,2),(1,1),(2,0),(0,3),...,(4,0), zeros where the model has no term.  Conditional mean_k = x_k + Q_{e_k}.
+ * Rows 14, 15 hold the conditional variances of X'_0, X'_1 (diagonal of tme.mean_and_cov, moments.py:469-476), read in
+ * scaled mode only.
  *
  * MFS_ND_TRANS_GAUSSIAN ('index' signature, the Normal closures sde_cond_moments_tme_normal / _euler_maruyama,
  * mfs/multi_dims/moments.py:340-411, 257-337, whose moments the reference takes from Kan's formula, :110-154):
@@ -198,30 +199,32 @@ int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean
  *   multi_indices  [z][2] int32, must equal the graded-lex table (checked: MFS_EINVAL otherwise, mirroring the
  *                  reference's only raise, multi_dims/filtering.py:238-239)
  *   inds           [3][s][s] int32 Gram / Hankel gather tables (gram_and_hankel_indices_graded_lexico)
- *   m0 [z] or [B][z]; mean0 [2] or [B][2] (central mode); ys [B][T]
- *   out_moments [B][T][z]; out_means [B][T][2] (central; NULL in raw mode); out_nell [B]; out_first_nan [B]
+ *   m0 [z] or [B][z]; mean0 [2] or [B][2] (central, scaled); scale0 likewise (scaled); ys [B][T]
+ *   out_moments [B][T][z]; out_means [B][T][2] (central, scaled; NULL in raw mode); out_scales [B][T][2] (scaled);
+ *   out_nell [B]; out_first_nan [B]
  */
 #define MFS_ND_TERMS 14
+#define MFS_ND_ROWS 16 /* coefficient blocks passed: MFS_ND_TERMS operator terms + 2 variance rows */
 #define MFS_ND_MAX_EXTENT 6
 #define MFS_ND_TRANS_OPERATOR 0
 #define MFS_ND_TRANS_GAUSSIAN 1
 typedef struct mfs_model_nd {
     int32_t d;             /* 2 */
     int32_t trans_kind;    /* MFS_ND_TRANS_* */
-    int32_t n_terms;       /* MFS_ND_TERMS rows are always passed; terms >= n_terms are known to be zero */
+    int32_t n_terms;       /* MFS_ND_ROWS blocks are always passed; operator terms >= n_terms are known to be zero */
     int32_t extent;        /* D <= MFS_ND_MAX_EXTENT */
     int32_t lik_kind;      /* MFS_LIK_* */
     int32_t n_lik;
     int32_t lik_component; /* which state component the likelihood reads */
     int32_t reserved;      /* 0 */
-    const double* coef;    /* [MFS_ND_TERMS][D][D] */
+    const double* coef;    /* [MFS_ND_ROWS][D][D] */
     const double* lik;     /* [n_lik] */
 } mfs_model_nd;
 
 int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z, const int32_t* multi_indices,
-                  const int32_t* inds, const double* m0, int m0_batched, const double* mean0, const double* ys,
-                  int stable, double* out_moments, double* out_means, double* out_nell, int32_t* out_first_nan,
-                  int device, void* stream);
+                  const int32_t* inds, const double* m0, int m0_batched, const double* mean0, const double* scale0,
+                  const double* ys, int stable, double* out_moments, double* out_means, double* out_scales,
+                  double* out_nell, int32_t* out_first_nan, int device, void* stream);
 
 /*
  * ---- multi-GPU: one process per GPU, replicates sharded, NLL all-gather over RCCL / xGMI -----------------------

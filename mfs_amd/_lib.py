@@ -34,6 +34,7 @@ class MfsModelNd(C.Structure):
 
 
 ND_TERMS = 14
+ND_ROWS = 16
 ND_TRANS_OPERATOR, ND_TRANS_GAUSSIAN = 0, 1
 ND_MAX_EXTENT = 6
 # derivative multi-indices kappa, 1 <= |kappa| <= 4, graded-lex (the order of mfs_model_nd.coef rows)
@@ -76,8 +77,8 @@ _SIGNATURES = [
                                   C.POINTER(C.c_int)]),
     ('mfs_quadrature_1d', _i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     ('mfs_characteristic_1d', _i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
-    ('mfs_filter_nd', _i, [C.POINTER(MfsModelNd), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i,
-                           _vp, _vp, _vp, _vp, _i, _vp]),
+    ('mfs_filter_nd', _i, [C.POINTER(MfsModelNd), _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i,
+                           _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     ('mfs_comm_unique_id', _i, [_vp]),
     ('mfs_comm_init', _i, [_vpp, _vp, _i, _i, _i]),
     ('mfs_allgather_nell', _i, [_vp, _vp, _vp, _u64, _vp]),

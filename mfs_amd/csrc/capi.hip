@@ -498,12 +498,13 @@ int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z,
                              const int32_t* multi_indices, const int32_t* inds, const double* m0, int m0_batched,
-                             const double* mean0, const double* ys, int stable, double* out_moments,
-                             double* out_means, double* out_nell, int32_t* out_first_nan, int device, void* stream) {
+                             const double* mean0, const double* scale0, const double* ys, int stable,
+                             double* out_moments, double* out_means, double* out_scales, double* out_nell,
+                             int32_t* out_first_nan, int device, void* stream) {
     if (!model) return fail(MFS_EINVAL, "model is NULL");
     if (model->d != 2) return fail(MFS_EUNSUPPORTED, "the device N-D path supports d = 2 (got %d)", model->d);
-    if (mode != MFS_MODE_RAW && mode != MFS_MODE_CENTRAL)
-        return fail(MFS_EUNSUPPORTED, "the device N-D path supports raw and central moments");
+    if (mode != MFS_MODE_RAW && mode != MFS_MODE_CENTRAL && mode != MFS_MODE_SCALED)
+        return fail(MFS_EINVAL, "unknown moment mode %d", mode);
     if (N < 2 || N > 7) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, 7] for d = 2", N);
     const mfs::NdEntry& ke = mfs::g_nd_table[N];
     if (!ke.launch) return fail(MFS_EUNSUPPORTED, "no N-D kernel compiled for N = %d", N);
@@ -521,7 +522,8 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (!multi_indices || !inds || !m0 || !out_nell || !model->coef || !model->lik || (T > 0 && B > 0 && !ys))
         return fail(MFS_EINVAL, "NULL buffer");
-    if (mode == MFS_MODE_CENTRAL && !mean0) return fail(MFS_EINVAL, "mean0 is required in central mode");
+    if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
+    if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
     // the kernel derives a moment's multi-index from its position: insist on the graded-lex table
     for (int s = 0, zi = 0; s < 2 * N; ++s)
         for (int n0 = 0; n0 <= s; ++n0, ++zi)
@@ -532,7 +534,7 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     hipStream_t s = (hipStream_t)stream;
     const size_t S = ke.S, Z = ke.Z, nb = m0_batched ? B : 1, DD = (size_t)model->extent * model->extent;
     double *d_coef = nullptr, *d_lik = nullptr, *d_m0 = nullptr, *d_mean0 = nullptr, *d_ys = nullptr, *d_mom = nullptr,
-           *d_means = nullptr, *d_nell = nullptr;
+           *d_means = nullptr, *d_nell = nullptr, *d_scale0 = nullptr, *d_scales = nullptr;
     int32_t *d_inds = nullptr, *d_fn = nullptr;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
@@ -542,21 +544,24 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     auto d2h = [&](void* h, const void* d, size_t bytes) {
         if (e == hipSuccess && h && d && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
     };
-    alloc((void**)&d_coef, MFS_ND_TERMS * DD * 8);
+    alloc((void**)&d_coef, MFS_ND_ROWS * DD * 8);
     alloc((void**)&d_lik, model->n_lik * 8);
     alloc((void**)&d_inds, 3 * S * S * 4);
     alloc((void**)&d_m0, nb * Z * 8);
     alloc((void**)&d_mean0, nb * 2 * 8);
+    alloc((void**)&d_scale0, nb * 2 * 8);
     alloc((void**)&d_ys, (size_t)B * T * 8);
     if (out_moments) alloc((void**)&d_mom, (size_t)B * T * Z * 8);
-    if (out_means && mode == MFS_MODE_CENTRAL) alloc((void**)&d_means, (size_t)B * T * 2 * 8);
+    if (out_means && mode != MFS_MODE_RAW) alloc((void**)&d_means, (size_t)B * T * 2 * 8);
+    if (out_scales && mode == MFS_MODE_SCALED) alloc((void**)&d_scales, (size_t)B * T * 2 * 8);
     alloc((void**)&d_nell, (size_t)B * 8);
     alloc((void**)&d_fn, (size_t)B * 4);
-    h2d(d_coef, model->coef, MFS_ND_TERMS * DD * 8);
+    h2d(d_coef, model->coef, MFS_ND_ROWS * DD * 8);
     h2d(d_lik, model->lik, model->n_lik * 8);
     h2d(d_inds, inds, 3 * S * S * 4);
     h2d(d_m0, m0, nb * Z * 8);
     if (mean0) h2d(d_mean0, mean0, nb * 2 * 8);
+    if (scale0 && mode == MFS_MODE_SCALED) h2d(d_scale0, scale0, nb * 2 * 8);
     h2d(d_ys, ys, (size_t)B * T * 8);
     if (e == hipSuccess) {
         mfs::FilterNdArgs a;
@@ -564,24 +569,25 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
         a.mode = mode; a.T = T; a.B = B; a.stable = stable;
         a.n_terms_used = model->n_terms; a.D = model->extent;
         a.lik_kind = model->lik_kind; a.n_lik = model->n_lik; a.lik_component = model->lik_component;
-        for (int k = 0; k < MFS_ND_TERMS; ++k) {  // true extents of each Q_kappa block (trailing zero rows / columns cut)
+        for (int k = 0; k < MFS_ND_ROWS; ++k) {  // true extents of each Q_kappa block (trailing zero rows / columns cut)
             int ea = 0, eb = 0;
             for (int i = 0; i < model->extent; ++i)
                 for (int j = 0; j < model->extent; ++j)
                     if (model->coef[(size_t)k * DD + i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
             a.ext[k] = (ea == 0) ? 0 : (ea | (eb << 8));
         }
-        a.coef = d_coef; a.lik = d_lik; a.inds = d_inds; a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0;
-        a.ys = d_ys; a.out_mom = d_mom; a.out_mean = d_means; a.out_nell = d_nell; a.out_first_nan = d_fn;
+        a.coef = d_coef; a.lik = d_lik; a.inds = d_inds; a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0;
+        a.ys = d_ys; a.out_mom = d_mom; a.out_mean = d_means; a.out_scale = d_scales; a.out_nell = d_nell; a.out_first_nan = d_fn;
         e = (model->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : ke.launch)(a, B, s);
     }
     d2h(out_moments, d_mom, (size_t)B * T * Z * 8);
     d2h(out_means, d_means, (size_t)B * T * 2 * 8);
+    d2h(out_scales, d_scales, (size_t)B * T * 2 * 8);
     d2h(out_nell, d_nell, (size_t)B * 8);
     d2h(out_first_nan, d_fn, (size_t)B * 4);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     hipFree(d_coef); hipFree(d_lik); hipFree(d_inds); hipFree(d_m0); hipFree(d_mean0); hipFree(d_ys); hipFree(d_mom);
-    hipFree(d_means); hipFree(d_nell); hipFree(d_fn);
+    hipFree(d_means); hipFree(d_nell); hipFree(d_fn); hipFree(d_scale0); hipFree(d_scales);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
     return MFS_OK;
 }

@@ -32,22 +32,26 @@ struct FilterNdArgs {
     int mode, T, B, stable;
     int n_terms_used, D;      // coefficient block extent per variable (degree + 1)
     int lik_kind, n_lik, lik_component;
-    int ext[14];              // per-term true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
-    const double* coef;       // [kNdTerms][D][D] in the fixed kappa order below (zeros where the model has no term)
+    int ext[16];              // per-block true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
+    const double* coef;       // [kNdRows][D][D]: rows 0..13 Q_kappa in the fixed kappa order below (zeros where the
+                              // model has no term), rows 14, 15 the conditional variances of X'_0, X'_1 (scaled mode)
     const double* lik;        // [n_lik]
     const int32_t* inds;      // [3][s][s]
     const double* m0;         // [z] or [B][z]
     int m0_batched;
     const double* mean0;      // [2] or [B][2]
+    const double* scale0;     // [2] or [B][2] (scaled mode)
     const double* ys;         // [B][T]
     double* out_mom;          // [B][T][z]
     double* out_mean;         // [B][T][2]
+    double* out_scale;        // [B][T][2] (scaled mode)
     double* out_nell;
     int32_t* out_first_nan;
 };
 
 // derivative multi-indices kappa with 1 <= |kappa| <= 4, graded-lex order (the order the host fills `coef` in)
 constexpr int kNdTerms = 14;
+constexpr int kNdRows = 16;
 constexpr int kNdMaxD = 6;
 __device__ constexpr int kKap0[kNdTerms] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 __device__ constexpr int kKap1[kNdTerms] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
@@ -74,9 +78,10 @@ struct NdTile {
     static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
     static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] node weights
     static constexpr int oLam = oW + ((R + 1) & ~1); // [2][NP]
-    static constexpr int oRed = oLam + 2 * NP;       // [4 waves][Z + 4]
-    static constexpr int oCoef = oRed + 4 * (Z + 4); // [kNdTerms][D][D]
-    static constexpr int oMisc = oCoef + kNdTerms * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
+    static constexpr int RW = Z + 6;                 // per-wave reduction row: moments, flag, 5 scalar sums
+    static constexpr int oRed = oLam + 2 * NP;       // [4 waves][RW]
+    static constexpr int oCoef = oRed + 4 * RW;      // [kNdRows][D][D]
+    static constexpr int oMisc = oCoef + kNdRows * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
     static constexpr int kDoubles = oMisc + 8;
 };
 
@@ -449,15 +454,16 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
 template <int N, int TK>
 __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N>;
-    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R;
+    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R, RW = L::RW;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
     const int tid = threadIdx.x, b = blockIdx.x;
+    const bool scaled = a.mode == MFS_MODE_SCALED;
     double* mom = Sm + L::oMom;
     const double* coef = Sm + L::oCoef;
     const double* lp = Sm + L::oMisc;
     const int DD = a.D * a.D;
 
-    for (int e = tid; e < kNdTerms * DD; e += 256) Sm[L::oCoef + e] = a.coef[e];
+    for (int e = tid; e < kNdRows * DD; e += 256) Sm[L::oCoef + e] = a.coef[e];
     if (tid < 4) Sm[L::oMisc + tid] = (tid < a.n_lik) ? a.lik[tid] : 0.0;
     {
         const double* src = a.m0 + (a.m0_batched ? (size_t)b * Z : 0);
@@ -466,7 +472,9 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
     // every thread carries an identical copy of the block-uniform state (mean, nell): they are all computed from the
     // same LDS-reduced sums, so no broadcast is ever needed
     double mean0 = 0.0, mean1 = 0.0, nell = 0.0;
+    double scale0 = 1.0, scale1 = 1.0;
     if (a.mode != MFS_MODE_RAW) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
+    if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
     double* red = Sm + L::oRed;
     if (tid == 0) red[Z] = 0.0;
     __syncthreads();
@@ -489,12 +497,13 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 const double* lam = Sm + L::oLam;
                 const double* W = Sm + L::oW;
                 const double qm0 = mean0, qm1 = mean1;  // the centre this quadrature's nodes are built around
+                const double qs0 = scale0, qs1 = scale1; // and their scales (1 unless scaled mode)
                 // ---- pass 1: the scalar sums (conditional means, or p_y and the posterior mean)
-                double s0 = 0.0, s1 = 0.0, s4 = 0.0;
+                double s0 = 0.0, s1 = 0.0, s4 = 0.0, s2 = 0.0, s3 = 0.0;
                 for (int e = tid; e < R; e += 256) {
                     const int i0 = e / S, i1 = e - i0 * S;
                     const double w = W[e];
-                    const double x0 = lam[i0] + qm0, x1 = lam[NP + i1] + qm1;
+                    const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[NP + i1], qs1, qm1);
                     if (half == 0) {
                         if constexpr (TK == 0) {
                             s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
@@ -503,20 +512,28 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                             s0 = fma(w, poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s0);       // mu_0(x)
                             s1 = fma(w, poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s1);       // mu_1(x)
                         }
+                        if (scaled) {  // scale <- sqrt(sum w var_k(x)), filtering.py:186
+                            constexpr int v0 = (TK == 0) ? 14 : 2, v1 = (TK == 0) ? 15 : 4;
+                            s2 = fma(w, poly2d(coef + v0 * DD, a.D, a.ext[v0], x0, x1), s2);
+                            s3 = fma(w, poly2d(coef + v1 * DD, a.D, a.ext[v1], x0, x1), s3);
+                        }
                     } else {
                         const double wl = w * likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
                         s0 = fma(wl, x0, s0); s1 = fma(wl, x1, s1); s4 += wl;
                     }
                 }
                 s0 = wave_sum64(s0); s1 = wave_sum64(s1); s4 = wave_sum64(s4);
+                if (scaled && half == 0) { s2 = wave_sum64(s2); s3 = wave_sum64(s3); }
                 if ((tid & 63) == 0) {
-                    double* r3 = red + (Z + 4) * (tid >> 6);
-                    r3[Z + 1] = s0; r3[Z + 2] = s1; r3[Z + 3] = s4;
+                    double* r3 = red + RW * (tid >> 6);
+                    r3[Z + 1] = s0; r3[Z + 2] = s1; r3[Z + 3] = s4; r3[Z + 4] = s2; r3[Z + 5] = s3;
                 }
                 __syncthreads();
-                s0 = red[Z + 1] + red[(Z + 4) + Z + 1] + red[2 * (Z + 4) + Z + 1] + red[3 * (Z + 4) + Z + 1];
-                s1 = red[Z + 2] + red[(Z + 4) + Z + 2] + red[2 * (Z + 4) + Z + 2] + red[3 * (Z + 4) + Z + 2];
-                s4 = red[Z + 3] + red[(Z + 4) + Z + 3] + red[2 * (Z + 4) + Z + 3] + red[3 * (Z + 4) + Z + 3];
+                s0 = red[Z + 1] + red[RW + Z + 1] + red[2 * RW + Z + 1] + red[3 * RW + Z + 1];
+                s1 = red[Z + 2] + red[RW + Z + 2] + red[2 * RW + Z + 2] + red[3 * RW + Z + 2];
+                s4 = red[Z + 3] + red[RW + Z + 3] + red[2 * RW + Z + 3] + red[3 * RW + Z + 3];
+                s2 = red[Z + 4] + red[RW + Z + 4] + red[2 * RW + Z + 4] + red[3 * RW + Z + 4];
+                s3 = red[Z + 5] + red[RW + Z + 5] + red[2 * RW + Z + 5] + red[3 * RW + Z + 5];
                 double c0 = 0.0, c1 = 0.0, py = 1.0;
                 if (half == 0) {
                     if (a.mode != MFS_MODE_RAW) { c0 = s0; c1 = s1; }
@@ -544,8 +561,8 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                             const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
                             wA = okA ? W[eA] : 0.0;
                             wB = okB ? W[eB] : 0.0;
-                            const double xA0 = lam[iA0] + qm0, xA1 = lam[NP + iA1] + qm1;
-                            const double xB0 = lam[iB0] + qm0, xB1 = lam[NP + iB1] + qm1;
+                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
+                            const double xB0 = fma(lam[iB0], qs0, qm0), xB1 = fma(lam[NP + iB1], qs1, qm1);
                             mA0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xA0, xA1) - c0;
                             mA1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xA0, xA1) - c1;
                             sA00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xA0, xA1);
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                                 const int sdeg = n0 + n1, zi = sdeg * (sdeg + 1) / 2 + n0;
                                 const double v = wave_sum64(fma(wA, vA, wB * vB));
                                 if ((tid & 63) == 0) {
-                                    double* slot = red + (tid >> 6) * (Z + 4) + zi;
+                                    double* slot = red + (tid >> 6) * RW + zi;
                                     *slot = (base == 0) ? v : *slot + v;
                                 }
                             }
@@ -604,8 +621,8 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                         const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
                         wA = okA ? W[eA] : 0.0;
                         wB = okB ? W[eB] : 0.0;
-                        const double xA0 = lam[iA0] + qm0, xA1 = lam[NP + iA1] + qm1;
-                        const double xB0 = lam[iB0] + qm0, xB1 = lam[NP + iB1] + qm1;
+                        const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
+                        const double xB0 = fma(lam[iB0], qs0, qm0), xB1 = fma(lam[NP + iB1], qs1, qm1);
                         pxA0[0] = pxA1[0] = pxB0[0] = pxB1[0] = 1.0;
 #pragma unroll
                         for (int p = 1; p < P; ++p) {
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                             }
                             const double v = wave_sum64(fma(wA, vA, wB * vB));
                             if ((tid & 63) == 0) {
-                                double* slot = red + (tid >> 6) * (Z + 4) + zi;
+                                double* slot = red + (tid >> 6) * RW + zi;
                                 *slot = (base == 0) ? v : *slot + v;
                             }
                         }
@@ -651,13 +668,36 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 }
                 __syncthreads();
                 const double ipy = 1.0 / py;
+                // scaled mode: the sums above are central moments about the new mean; the new scales are
+                // sqrt(sum w var_k) on prediction (filtering.py:186) and the posterior standard deviations on update
+                // (:195-197), and every moment is divided by prod_k scale_k^{n_k} -- the same numbers as forming
+                // ((x - mean) / scale)^n per node (:177, :187, :198-200)
+                double ns0 = 1.0, ns1 = 1.0;
+                if (scaled) {
+                    if (half == 0) { ns0 = sqrt(s2); ns1 = sqrt(s3); }
+                    else {
+                        ns0 = sqrt((red[5] + red[RW + 5] + red[2 * RW + 5] + red[3 * RW + 5]) * ipy);   // (2, 0)
+                        ns1 = sqrt((red[3] + red[RW + 3] + red[2 * RW + 3] + red[3 * RW + 3]) * ipy);   // (0, 2)
+                    }
+                }
                 for (int zi = tid; zi < Z; zi += 256) {
-                    double v = red[zi] + red[(Z + 4) + zi] + red[2 * (Z + 4) + zi] + red[3 * (Z + 4) + zi];
+                    double v = red[zi] + red[RW + zi] + red[2 * RW + zi] + red[3 * RW + zi];
                     v = (half == 0) ? v : v * ipy;
+                    if (scaled) {
+                        int sd = 0;
+                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                        const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
+                        double f = 1.0;
+                        for (int q = 0; q < n0; ++q) f *= i0;
+                        for (int q = 0; q < n1; ++q) f *= i1;
+                        v *= f;
+                    }
                     mom[zi] = v;
                     if (!finite(v)) red[Z] = 1.0;  // slot Z of the first row flags a non-finite moment
                 }
                 if (a.mode != MFS_MODE_RAW) { mean0 = c0; mean1 = c1; }
+                if (scaled) { scale0 = ns0; scale1 = ns1; }
                 __syncthreads();
                 bad = bad || poisoned || (red[Z] != 0.0);
                 __syncthreads();
@@ -667,11 +707,12 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
 #endif
             }
-            bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1);
+            bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1) || !finite(scale0) || !finite(scale1);
             if (bad) { dead = true; first_nan = t; }
         } else {
             for (int zi = tid; zi < Z; zi += 256) mom[zi] = qnan;
             mean0 = mean1 = nell = qnan;
+            if (scaled) scale0 = scale1 = qnan;
         }
         __syncthreads();
         if (a.out_mom) {
@@ -681,6 +722,10 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
         if (tid == 0 && a.out_mean) {
             a.out_mean[((size_t)b * a.T + t) * 2] = mean0;
             a.out_mean[((size_t)b * a.T + t) * 2 + 1] = mean1;
+        }
+        if (tid == 0 && a.out_scale) {
+            a.out_scale[((size_t)b * a.T + t) * 2] = scale0;
+            a.out_scale[((size_t)b * a.T + t) * 2 + 1] = scale1;
         }
     }
     if (tid == 0) {

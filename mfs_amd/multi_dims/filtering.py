@@ -35,6 +35,9 @@ def _trace_transition(fn_and_flag, mode, moments_partial_order=None):
     if mode == 'raw':
         ref = fn(sym.X, second)
         ok = isinstance(ref, TransitionRefND) and ref.mean is None
+    elif mode == 'scaled':
+        ref = fn(sym.X, second, sym.MEAN, sym.SCALE)
+        ok = isinstance(ref, TransitionRefND) and ref.mean is sym.MEAN and ref.scale is sym.SCALE
     else:
         ref = fn(sym.X, second, sym.MEAN)
         ok = isinstance(ref, TransitionRefND) and ref.mean is sym.MEAN
@@ -43,7 +46,7 @@ def _trace_transition(fn_and_flag, mode, moments_partial_order=None):
                                        'mfs_amd.multi_dims.moments.sde_cond_moments_tme / _tme_normal / '
                                        '_euler_maruyama')
     if not ok:
-        raise sym.NotDeviceDescribable('the transition-moment callable does not forward its mean argument')
+        raise sym.NotDeviceDescribable('the transition-moment callable does not forward its mean / scale arguments')
     gaussian = isinstance(ref.tables, GaussianTablesND)
     if gaussian != (signature == 'index'):
         raise sym.NotDeviceDescribable(f"signature {signature!r} does not match the closure: the Normal closures take "
@@ -79,7 +82,7 @@ def _model_struct(tables, lik: sym.LikelihoodSpec):
     dense, D = tables.dense_table()
     if D > _lib.ND_MAX_EXTENT:
         raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds MFS_ND_MAX_EXTENT = {_lib.ND_MAX_EXTENT}')
-    coef = np.zeros((_lib.ND_TERMS, D, D))
+    coef = np.zeros((_lib.ND_ROWS, D, D))
     if isinstance(tables, GaussianTablesND):
         coef[:5] = dense        # mu_0, mu_1, S_00, S_01, S_11
         kind, last = _lib.ND_TRANS_GAUSSIAN, 5
@@ -93,6 +96,9 @@ def _model_struct(tables, lik: sym.LikelihoodSpec):
             row = _lib.ND_KAPPAS.index(kap)
             coef[row] = dense[t]
             last = max(last, row + 1)
+        for k, v in enumerate(tables.var):      # diagonal of tme.mean_and_cov (scaled mode reads it)
+            blk = np.atleast_2d(v.coef)
+            coef[_lib.ND_TERMS + k, :blk.shape[0], :blk.shape[1]] = blk
     lp = np.ascontiguousarray(lik.params, dtype=np.float64)
     if lp.ndim != 1:
         raise sym.NotDeviceDescribable('per-replicate likelihood parameters are not supported on the N-D path yet')
@@ -105,7 +111,7 @@ def _model_struct(tables, lik: sym.LikelihoodSpec):
     return m, (coef, lp)
 
 
-def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, device):
+def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, device, scale0=None):
     multi_indices, inds = moments_partial_order
     multi_indices = np.asarray(multi_indices)
     ms0 = np.ascontiguousarray(ms0, dtype=np.float64)
@@ -125,23 +131,30 @@ def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, de
     if batched and ms0.shape[0] != B:
         raise ValueError(f'initial moments batch {ms0.shape[0]} does not match ys batch {B}')
     z = multi_indices.shape[0]
-    mean_a = None
-    if mode == 'central':
+    mean_a = scale_a = None
+    if mode != 'raw':
         mean_a = np.ascontiguousarray(np.broadcast_to(np.asarray(mean0, dtype=np.float64), ((B, 2) if batched else (2,))))
+    if mode == 'scaled':
+        scale_a = np.ascontiguousarray(np.broadcast_to(np.asarray(scale0, dtype=np.float64),
+                                                       ((B, 2) if batched else (2,))))
     model, keep = _model_struct(tables, lik)
     mi32 = np.ascontiguousarray(multi_indices, dtype=np.int32)
     inds32 = np.ascontiguousarray(inds, dtype=np.int32)
     out_m = np.empty((B, T, z))
-    out_mean = np.empty((B, T, 2)) if mode == 'central' else None
+    out_mean = np.empty((B, T, 2)) if mode != 'raw' else None
+    out_scale = np.empty((B, T, 2)) if mode == 'scaled' else None
     out_nell, out_fn = np.empty((B,)), np.empty((B,), dtype=np.int32)
     _lib.check(_lib.lib().mfs_filter_nd(C.byref(model), _lib.MODE[mode], N, T, B, z, _lib.ptr(mi32), _lib.ptr(inds32),
-                                        _lib.ptr(ms0), int(batched), _lib.ptr(mean_a), _lib.ptr(ys2),
-                                        int(bool(stable)), _lib.ptr(out_m), _lib.ptr(out_mean), _lib.ptr(out_nell),
-                                        _lib.ptr(out_fn), device, None))
+                                        _lib.ptr(ms0), int(batched), _lib.ptr(mean_a), _lib.ptr(scale_a), _lib.ptr(ys2),
+                                        int(bool(stable)), _lib.ptr(out_m), _lib.ptr(out_mean), _lib.ptr(out_scale),
+                                        _lib.ptr(out_nell), _lib.ptr(out_fn), device, None))
     del keep
     if squeeze:
         out_m, out_nell, out_fn = out_m[0], out_nell[0], out_fn[0]
         out_mean = None if out_mean is None else out_mean[0]
+        out_scale = None if out_scale is None else out_scale[0]
+    if mode == 'scaled':
+        return out_m, out_mean, out_scale, out_nell, out_fn
     return out_m, out_mean, out_nell, out_fn
 
 
@@ -169,7 +182,17 @@ def moment_filter_nd_cms(state_cond_central_moments: Tuple[Callable, str], state
     return (m, means, nell, fn) if return_first_nan else (m, means, nell)
 
 
-def moment_filter_nd_scms(*args, **kwargs):
-    """Scaled-central N-D filter (mfs/multi_dims/filtering.py:33-207).  Not on the device: no reference driver uses
-    it (dardel/prey_predator/mf.py:70 raises NotImplementedError for it) -- raises rather than falling back."""
-    raise sym.NotDeviceDescribable('moment_filter_nd_scms is not implemented on the device (raw and central are)')
+def moment_filter_nd_scms(state_cond_scms: Tuple[Callable, str], state_cond_mean_vars: Callable,
+                          measurement_cond_pdf: Callable, ys, moments_partial_order, scms0, mean0, scale0,
+                          stable: bool = False, *, device: int = 0, return_first_nan: bool = False):
+    """Filtering with scaled central moments (mfs/multi_dims/filtering.py:33-207): returns
+    (scmss (T, z), means (T, d), scales (T, d), nell)."""
+    tables = _trace_transition(state_cond_scms, 'scaled', moments_partial_order)
+    ref = state_cond_mean_vars(sym.X)
+    if not (isinstance(ref, TransitionRefND) and ref.tables is tables and ref.which == 'mean_var'):
+        raise sym.NotDeviceDescribable('state_cond_mean_vars must be the mean-and-variance closure of the same '
+                                       'sde_cond_moments_* call as the conditional scaled moments')
+    lik = _trace_likelihood(measurement_cond_pdf, tables.d)
+    m, means, scales, nell, fn = _run_nd('scaled', tables, lik, ys, moments_partial_order, scms0, mean0, stable, device,
+                                         scale0)
+    return (m, means, scales, nell, fn) if return_first_nan else (m, means, scales, nell)

@@ -200,7 +200,7 @@ class TransitionTablesND:
 
     def dense_table(self):
         """(n_terms, D, D, ...) coefficient block with a common per-variable degree bound D - 1."""
-        D = max(max(p.coef.shape) for p in self.Q)
+        D = max(max(np.atleast_1d(p.coef).shape) for p in list(self.Q) + list(self.var))
         out = np.zeros((len(self.Q),) + (D,) * self.d)
         for t, p in enumerate(self.Q):
             out[(t,) + tuple(slice(0, n) for n in p.coef.shape)] = p.coef

@@ -80,8 +80,6 @@ def test_nd_shapes_errors_and_single_trajectory():
         filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms[:-1], gs.mean)
     with pytest.raises(sym.NotDeviceDescribable):
         filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
-    with pytest.raises(sym.NotDeviceDescribable):
-        filtering.moment_filter_nd_scms()
     # NaN poisoning is per replicate
     cms0 = np.tile(gs.cms, (2, 1))
     cms0[0, 5] = -1.  # E[(x0 - m0)^2] < 0
@@ -119,3 +117,47 @@ def test_prey_predator_normal_closures(N, T, order):
     # a closure declared with the wrong signature, or built for another table, is refused
     with pytest.raises(sym.NotDeviceDescribable):
         filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
+
+
+@pytest.mark.parametrize('N,T,family', [(3, 50, 'tme_2'), (4, 30, 'tme_2'), (3, 50, 'tme_normal_2'), (6, 10, 'tme_2')])
+def test_prey_predator_scaled_mode(N, T, family):
+    """moment_filter_nd_scms (mfs/multi_dims/filtering.py:33-207) against the oracle, and the reference's own
+    three-mode equivalence (tests/test_filtering.py:168-242: means of the scaled and central filters agree)."""
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    _, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    if family == 'tme_2':
+        fns, sig = moments.sde_cond_moments_tme(drift, disp, dt, 2), 'multi-index'
+        _, ocms, _, omean_var = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, 2, mi)
+    else:
+        fns, sig = moments.sde_cond_moments_tme_normal(drift, disp, dt, 2, mi), 'index'
+        _, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(odrift, odisp, 2, dt, 2, mi)
+        tab = fns[4].tables
+
+        def omean_var(x):
+            return omean(x), tab.cond_var(x)   # diag of the same polynomial covariance (checked on the CPU suite)
+
+    def oscms(x, idx, mean, scale):
+        sel = mi[np.asarray(idx)] if sig == 'index' else np.asarray(idx)
+        return ocms(x, idx, mean) / np.prod(np.asarray(scale) ** sel, axis=-1)
+
+    scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))           # (2, 0) and (0, 2)
+    scms0 = gs.cms / np.prod(scale0 ** mi, axis=-1)
+    B = 2
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=20 + N)
+    scmss, means, scales, nell = filtering.moment_filter_nd_scms((fns[2], sig), fns[4], pmf, ys, (mi, inds), scms0,
+                                                                 gs.mean, scale0)
+    assert scmss.shape == (B, T, mi.shape[0]) and means.shape == (B, T, 2) and scales.shape == (B, T, 2)
+    cmss, means_c, nell_c = filtering.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
+    npt.assert_allclose(means, means_c, rtol=1e-7 if N <= 4 else 1e-5)
+    npt.assert_allclose(nell, nell_c, rtol=1e-7 if N <= 4 else 1e-5)
+    npt.assert_allclose(scales ** 2, np.stack([cmss[:, :, 5], cmss[:, :, 3]], axis=-1), rtol=1e-6 if N <= 4 else 1e-4)
+    npt.assert_allclose(scmss[:, :, 5], 1., rtol=1e-9)           # posterior scaled second moments are 1 by construction
+    rs = omd.moment_filter_nd_scms((oscms, sig), omean_var, opmf, ys[0], (mi, inds), scms0, ogs.mean, scale0)
+    npt.assert_allclose(nell[0], rs[3], rtol=1e-6)
+    npt.assert_allclose(means[0], rs[1], rtol=1e-6)
+    npt.assert_allclose(scales[0], rs[2], rtol=1e-6)
+    _assert_moments(scmss[0], rs[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
+    with pytest.raises(sym.NotDeviceDescribable):   # the mean-only closure is not the mean-and-variance closure
+        filtering.moment_filter_nd_scms((fns[2], sig), fns[3], pmf, ys, (mi, inds), scms0, gs.mean, scale0)
