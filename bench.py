@@ -36,6 +36,9 @@ WORKLOADS = {
     'benes_bernoulli_N7_T100_B4096_central_tme3': ('benes', 7, 100, 4096, 'central', 'tme_3'),
     'benes_bernoulli_N15_T1000_B4096_central_tme_normal3': ('benes', 15, 1000, 4096, 'central', 'tme_normal_3'),
     'well_poisson_N7_T1000_B131072_central_tme_normal2': ('well', 7, 1000, 131072, 'central', 'tme_normal_2'),
+    # BASELINE config 5 (d = 2): per-GPU shard of the 512-replicate batch is set with --B (128 on 4 GPUs)
+    'prey_predator_N6_T500_B512_central_tme2': ('prey', 6, 500, 512, 'central', 'tme_2'),
+    'prey_predator_N6_T500_B512_central_tme_normal2': ('prey', 6, 500, 512, 'central', 'tme_normal_2'),
 }
 DEFAULT_WORKLOAD = 'benes_bernoulli_N15_T1000_B4096_central_tme3'
 
@@ -100,6 +103,8 @@ def main():
     B = args.B or B
     T = args.T or T
     L = _lib.lib()
+    if model == 'prey':
+        return main_nd(args, rank, local_rank, world, N, T, B, mode, transition)
     # one GPU per rank; on a box with fewer GPUs than ranks (rehearsals only) ranks share devices and RCCL, which
     # refuses duplicate GPUs, falls back to the reported host gather
     device = local_rank % max(_lib.device_count(), 1)
@@ -217,6 +222,153 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, nell, first_nan)
         print(json.dumps(out))
     comm.close()
+
+
+def main_nd(args, rank, local_rank, world, N, T, B, mode, transition):
+    """BASELINE config 5: the d = 2 prey--predator filter through the device-pointer N-D plan."""
+    import ctypes as C
+    from mfs_amd import _lib, synth, dist
+    from mfs_amd.multi_dims import filtering, moments, ss_models
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+        gram_and_hankel_indices_graded_lexico
+    L = _lib.lib()
+    device = local_rank % max(_lib.device_count(), 1)
+    comm = dist.Communicator.from_env(device=device)
+    _lib.check(L.mfs_set_device(device))
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    z = mi.shape[0]
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    kind, order = transition.rsplit('_', 1)
+    if kind == 'tme':
+        fns, sig = moments.sde_cond_moments_tme(drift, disp, dt, int(order)), 'multi-index'
+    else:
+        fns, sig = moments.sde_cond_moments_tme_normal(drift, disp, dt, int(order), mi), 'index'
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=100 + rank)
+    tables = filtering._trace_transition((fns[{'raw': 0, 'central': 1, 'scaled': 2}[mode]], sig), mode, (mi, inds))
+    lik = filtering._trace_likelihood(pmf, 2)
+    mstruct, keep = filtering._model_struct(tables, lik)
+    scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))
+    m0 = {'raw': gs.rms, 'central': gs.cms, 'scaled': gs.cms / np.prod(scale0 ** mi, axis=-1)}[mode]
+    d_m0 = _lib.DeviceBuffer.from_array(np.ascontiguousarray(m0))
+    d_mean0 = _lib.DeviceBuffer.from_array(np.ascontiguousarray(gs.mean, dtype=np.float64))
+    d_scale0 = _lib.DeviceBuffer.from_array(scale0)
+    d_ys = _lib.DeviceBuffer.from_array(ys)
+    d_mom = None if args.no_moments else _lib.DeviceBuffer(B * T * z * 8)
+    d_means = _lib.DeviceBuffer(B * T * 2 * 8)
+    d_scales = _lib.DeviceBuffer(B * T * 2 * 8)
+    d_nell = _lib.DeviceBuffer(B * 8)
+    d_fn = _lib.DeviceBuffer(B * 4)
+    d_nell_all = _lib.DeviceBuffer(B * 8 * world)
+    mi32 = np.ascontiguousarray(mi, dtype=np.int32)
+    inds32 = np.ascontiguousarray(inds, dtype=np.int32)
+    plan = C.c_void_p()
+    _lib.check(L.mfs_plan_nd_create(C.byref(plan), C.byref(mstruct), _lib.MODE[mode], N, T, B, z, _lib.ptr(mi32),
+                                    _lib.ptr(inds32), 0, device))
+    geo = [C.c_int() for _ in range(3)]
+    _lib.check(L.mfs_plan_nd_geometry(plan, *[C.byref(g) for g in geo]))
+    stream = C.c_void_p()
+    _lib.check(L.mfs_stream_create(C.byref(stream)))
+    ev = [C.c_void_p() for _ in range(2 * max(args.steps, 1))]
+    for e in ev:
+        _lib.check(L.mfs_event_create(C.byref(e)))
+
+    def one_pass(i=None):
+        if i is not None:
+            _lib.check(L.mfs_event_record(ev[2 * i], stream))
+        _lib.check(L.mfs_plan_nd_run(plan, d_m0.ptr, 0, d_mean0.ptr, d_scale0.ptr, d_ys.ptr,
+                                     d_mom.ptr if d_mom else None, d_means.ptr, d_scales.ptr, d_nell.ptr, d_fn.ptr,
+                                     stream))
+        if i is not None:
+            _lib.check(L.mfs_event_record(ev[2 * i + 1], stream))
+        comm.allgather_nell(d_nell, d_nell_all, B, stream)
+
+    for _ in range(args.warmup):
+        one_pass()
+    _lib.check(L.mfs_stream_synchronize(stream))
+    comm.barrier()
+    _lib.check(L.mfs_device_synchronize())
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_pass(i)
+    _lib.check(L.mfs_stream_synchronize(stream))
+    _lib.check(L.mfs_device_synchronize())
+    comm.barrier()
+    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
+    kern_ms = []
+    for i in range(args.steps):
+        ms = C.c_float()
+        _lib.check(L.mfs_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
+        kern_ms.append(ms.value)
+    kern_ms_avg = float(np.mean(kern_ms)) if kern_ms else float('nan')
+    first_nan = d_fn.to_array((B,), np.int32)
+    nell = d_nell.to_array((B,))
+    live_steps = int(np.where(first_nan >= 0, first_nan + 1, T).sum())
+    live_total = comm.sum_over_ranks(live_steps)
+    alive_total = comm.sum_over_ranks(int((first_nan < 0).sum()))
+    nell_all = d_nell_all.to_array((world * B,))
+    gather_ok = bool(np.array_equal(nell_all[rank * B:(rank + 1) * B], nell, equal_nan=True))
+    if rank == 0:
+        nominal_steps = world * B * T
+        value = live_total * args.steps / elapsed
+        per_step = 8 * (z + (3 if mode == 'central' else 5 if mode == 'scaled' else 1)) if d_mom else 8 * 2
+        algo_bytes = live_steps * per_step + B * 8 * (z + 3)
+        hbm_gbs = algo_bytes / (kern_ms_avg * 1e-3) / 1e9
+        flops_step = 2.0e6 if N == 6 else None   # SURVEY section 8d figure for config 5
+        out = {
+            'metric': 'filter time-steps/sec', 'value': value, 'unit': 'filter-steps/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'model': None, 'd': 2, 'N': N, 'z': int(z), 'T': T,
+                       'replicates_per_gpu': B, 'mode': mode, 'transition': transition,
+                       'parallelism': f'replicate-sharded x{world}', 'threads_per_filter': geo[0].value,
+                       'grid': geo[1].value, 'lds_bytes_per_block': geo[2].value,
+                       'moments_streamed_out': d_mom is not None},
+            'nominal_value': nominal_steps * args.steps / elapsed, 'live_fraction': live_total / nominal_steps,
+            'replicates_alive_at_T': alive_total, 'replicates': world * B, 'nll_allgather_ok': gather_ok,
+            'nll_allgather': ('rccl ncclAllGather' if comm.data == 'rccl' and world > 1 else
+                              'single rank: device copy' if world == 1 else f'host fallback: {comm.rccl_error}'),
+            'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'mfs::filternd_kernel',
+                         'avg_launch_ms': kern_ms_avg, 'algorithmic_bytes_per_launch': algo_bytes,
+                         'note': 'latency-bound small-matrix recursion (Jacobi rounds), not HBM-bound'},
+        }
+        if flops_step:
+            tf = live_steps * flops_step / (kern_ms_avg * 1e-3) / 1e12
+            out['valu_fp64'] = {'achieved': tf, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': tf / FP64_VALU_PEAK_TFLOPS, 'algorithmic_flops_per_filter_step': flops_step}
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline_nd(args, N, T, mode, transition, mi, inds, ys, nell)
+        print(json.dumps(out))
+    _lib.check(L.mfs_plan_nd_destroy(plan))
+    comm.close()
+
+
+def cpu_baseline_nd(args, N, T, mode, transition, mi, inds, ys, dev_nell):
+    """The NumPy/LAPACK oracle (one core) on one replicate over a bounded number of steps; kind = "port"."""
+    from oracle import multi_dims as omd, tme_sympy
+    dt, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    kind, order = transition.rsplit('_', 1)
+    if kind == 'tme':
+        _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, int(order), mi)
+        sig = 'multi-index'
+    else:
+        _, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(odrift, odisp, 2, dt, int(order), mi)
+        sig = 'index'
+    steps = 4
+    t0 = time.perf_counter()
+    omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0, :steps], (mi, inds), ogs.cms, ogs.mean)
+    el = time.perf_counter() - t0
+    steps2 = int(min(T, max(steps, steps / el * args.cpu_seconds)))
+    t0 = time.perf_counter()
+    res = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0, :steps2], (mi, inds), ogs.cms, ogs.mean)
+    el = time.perf_counter() - t0
+    out = {'value': steps2 / el, 'unit': 'filter-steps/s', 'cores': 1, 'kind': 'port',
+           'sample': f'replicate 0, first {steps2} of T={T} steps of the same workload, oracle/multi_dims.py '
+                     f'(NumPy + LAPACK, lambdified SymPy transition), {el:.1f} s'}
+    if steps2 == T:
+        out['nll_rel_diff_vs_device'] = float(abs(res[2] - dev_nell[0]) / abs(res[2]))
+    return out
 
 
 def recorded_hbm_traffic(workload, moments_streamed):

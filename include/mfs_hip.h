@@ -227,6 +227,24 @@ int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int 
                   double* out_nell, int32_t* out_first_nan, int device, void* stream);
 
 /*
+ * ---- N-D plan: device pointers ------------------------------------------------------------------------------------
+ * The same filter for callers that keep data resident in HBM (benchmark harness, repeated calls of a jitted filter as
+ * in dardel/prey_predator/mf.py:54-65): model tables and gather indices are uploaded once at create; run() only
+ * enqueues the kernel on `stream`.  Device buffers have the layouts documented for mfs_filter_nd; d_out_moments,
+ * d_out_means, d_out_scales, d_out_first_nan may be NULL.
+ */
+typedef struct mfs_plan_nd mfs_plan_nd;
+
+int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model /* host pointers inside */, int mode, int N,
+                       int T, int B, int z, const int32_t* multi_indices, const int32_t* inds, int stable, int device);
+int mfs_plan_nd_run(mfs_plan_nd* plan, const double* d_m0, int m0_batched, const double* d_mean0,
+                    const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
+                    double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream);
+int mfs_plan_nd_destroy(mfs_plan_nd* plan);
+/* launch geometry: threads per filter (one workgroup each), grid size, dynamic LDS bytes per workgroup */
+int mfs_plan_nd_geometry(const mfs_plan_nd* plan, int* threads_per_filter, int* grid, int* lds_bytes_per_block);
+
+/*
  * ---- multi-GPU: one process per GPU, replicates sharded, NLL all-gather over RCCL / xGMI -----------------------
  * The reference has no multi-device code (its Monte-Carlo runs are separate OS processes,
  * dardel/run_benes_bernoulli_mf.sh:26-31); replicates share nothing, so the data path needs no collective and the

@@ -496,11 +496,18 @@ int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
 // ---------------------------------------------------------------------------------------------------------------
 // N-D filter (d = 2), host pointers
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z,
-                             const int32_t* multi_indices, const int32_t* inds, const double* m0, int m0_batched,
-                             const double* mean0, const double* scale0, const double* ys, int stable,
-                             double* out_moments, double* out_means, double* out_scales, double* out_nell,
-                             int32_t* out_first_nan, int device, void* stream) {
+struct mfs_plan_nd {
+    int mode, N, T, B, stable, device, trans_kind;
+    mfs::FilterNdArgs args;   // model part filled at create (device pointers), data pointers per run
+    double* d_coef = nullptr;
+    double* d_lik = nullptr;
+    int32_t* d_inds = nullptr;
+};
+
+extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model, int mode, int N, int T, int B, int z,
+                                  const int32_t* multi_indices, const int32_t* inds, int stable, int device) {
+    if (!plan) return fail(MFS_EINVAL, "plan is NULL");
+    *plan = nullptr;
     if (!model) return fail(MFS_EINVAL, "model is NULL");
     if (model->d != 2) return fail(MFS_EUNSUPPORTED, "the device N-D path supports d = 2 (got %d)", model->d);
     if (mode != MFS_MODE_RAW && mode != MFS_MODE_CENTRAL && mode != MFS_MODE_SCALED)
@@ -520,22 +527,101 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
         model->lik_component < 0 || model->lik_component > 1)
         return fail(MFS_EINVAL, "bad likelihood description");
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
-    if (!multi_indices || !inds || !m0 || !out_nell || !model->coef || !model->lik || (T > 0 && B > 0 && !ys))
-        return fail(MFS_EINVAL, "NULL buffer");
-    if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
-    if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    if (!multi_indices || !inds || !model->coef || !model->lik) return fail(MFS_EINVAL, "NULL buffer");
     // the kernel derives a moment's multi-index from its position: insist on the graded-lex table
     for (int s = 0, zi = 0; s < 2 * N; ++s)
         for (int n0 = 0; n0 <= s; ++n0, ++zi)
             if (multi_indices[2 * zi] != n0 || multi_indices[2 * zi + 1] != s - n0)
                 return fail(MFS_EINVAL, "multi_indices is not the graded-lexicographic table of order 2N-1");
-    if (B == 0) return MFS_OK;
     HIP_TRY(hipSetDevice(device));
+    mfs_plan_nd* p = new (std::nothrow) mfs_plan_nd();
+    if (!p) return fail(MFS_ENOMEM, "out of host memory");
+    p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device;
+    p->trans_kind = model->trans_kind;
+    const size_t S = ke.S, DD = (size_t)model->extent * model->extent;
+    hipError_t e = hipMalloc((void**)&p->d_coef, MFS_ND_ROWS * DD * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_lik, MFS_MAX_LIK * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_inds, 3 * S * S * 4);
+    if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, MFS_ND_ROWS * DD * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, model->n_lik * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_inds, inds, 3 * S * S * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->d_inds);
+        delete p;
+        return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_plan_nd_create: %s", hipGetErrorString(e));
+    }
+    mfs::FilterNdArgs& a = p->args;
+    memset(&a, 0, sizeof(a));
+    a.mode = mode; a.T = T; a.B = B; a.stable = stable;
+    a.n_terms_used = model->n_terms; a.D = model->extent;
+    a.lik_kind = model->lik_kind; a.n_lik = model->n_lik; a.lik_component = model->lik_component;
+    for (int k = 0; k < MFS_ND_ROWS; ++k) {  // true extents of each coefficient block (trailing zero rows / columns cut)
+        int ea = 0, eb = 0;
+        for (int i = 0; i < model->extent; ++i)
+            for (int j = 0; j < model->extent; ++j)
+                if (model->coef[(size_t)k * DD + i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
+        a.ext[k] = (ea == 0) ? 0 : (ea | (eb << 8));
+    }
+    a.coef = p->d_coef; a.lik = p->d_lik; a.inds = p->d_inds;
+    *plan = p;
+    return MFS_OK;
+}
+
+extern "C" int mfs_plan_nd_run(mfs_plan_nd* p, const double* d_m0, int m0_batched, const double* d_mean0,
+                               const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
+                               double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream) {
+    if (!p) return fail(MFS_EINVAL, "plan is NULL");
+    if (p->B == 0) return MFS_OK;
+    if (!d_m0 || !d_out_nell || (p->T > 0 && !d_ys)) return fail(MFS_EINVAL, "NULL buffer");
+    if (p->mode != MFS_MODE_RAW && !d_mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
+    if (p->mode == MFS_MODE_SCALED && !d_scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    HIP_TRY(hipSetDevice(p->device));
+    mfs::FilterNdArgs a = p->args;
+    a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
+    a.out_mom = d_out_moments;
+    a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
+    a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
+    a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
+    const mfs::NdEntry& ke = mfs::g_nd_table[p->N];
+    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : ke.launch)(a, p->B, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(MFS_EHIP, "mfs_plan_nd_run: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+extern "C" int mfs_plan_nd_destroy(mfs_plan_nd* p) {
+    if (!p) return MFS_OK;
+    hipSetDevice(p->device);
+    hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->d_inds);
+    delete p;
+    return MFS_OK;
+}
+
+extern "C" int mfs_plan_nd_geometry(const mfs_plan_nd* p, int* threads_per_filter, int* grid, int* lds_bytes_per_block) {
+    if (!p) return fail(MFS_EINVAL, "plan is NULL");
+    if (threads_per_filter) *threads_per_filter = 256;
+    if (grid) *grid = p->B;
+    if (lds_bytes_per_block) *lds_bytes_per_block = mfs::g_nd_table[p->N].lds_bytes;
+    return MFS_OK;
+}
+
+extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z,
+                             const int32_t* multi_indices, const int32_t* inds, const double* m0, int m0_batched,
+                             const double* mean0, const double* scale0, const double* ys, int stable,
+                             double* out_moments, double* out_means, double* out_scales, double* out_nell,
+                             int32_t* out_first_nan, int device, void* stream) {
+    mfs_plan_nd* plan = nullptr;
+    int rc = mfs_plan_nd_create(&plan, model, mode, N, T, B, z, multi_indices, inds, stable, device);
+    if (rc != MFS_OK) return rc;
+    struct Guard { mfs_plan_nd* p; ~Guard() { mfs_plan_nd_destroy(p); } } guard{plan};
+    if (!m0 || !out_nell || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "NULL buffer");
+    if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
+    if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    if (B == 0) return MFS_OK;
     hipStream_t s = (hipStream_t)stream;
-    const size_t S = ke.S, Z = ke.Z, nb = m0_batched ? B : 1, DD = (size_t)model->extent * model->extent;
-    double *d_coef = nullptr, *d_lik = nullptr, *d_m0 = nullptr, *d_mean0 = nullptr, *d_ys = nullptr, *d_mom = nullptr,
-           *d_means = nullptr, *d_nell = nullptr, *d_scale0 = nullptr, *d_scales = nullptr;
-    int32_t *d_inds = nullptr, *d_fn = nullptr;
+    const size_t Z = (size_t)z, nb = m0_batched ? B : 1;
+    double *d_m0 = nullptr, *d_mean0 = nullptr, *d_ys = nullptr, *d_mom = nullptr, *d_means = nullptr, *d_nell = nullptr,
+           *d_scale0 = nullptr, *d_scales = nullptr;
+    int32_t* d_fn = nullptr;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
     auto h2d = [&](void* d, const void* h, size_t bytes) {
@@ -544,9 +630,6 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     auto d2h = [&](void* h, const void* d, size_t bytes) {
         if (e == hipSuccess && h && d && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
     };
-    alloc((void**)&d_coef, MFS_ND_ROWS * DD * 8);
-    alloc((void**)&d_lik, model->n_lik * 8);
-    alloc((void**)&d_inds, 3 * S * S * 4);
     alloc((void**)&d_m0, nb * Z * 8);
     alloc((void**)&d_mean0, nb * 2 * 8);
     alloc((void**)&d_scale0, nb * 2 * 8);
@@ -556,38 +639,24 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     if (out_scales && mode == MFS_MODE_SCALED) alloc((void**)&d_scales, (size_t)B * T * 2 * 8);
     alloc((void**)&d_nell, (size_t)B * 8);
     alloc((void**)&d_fn, (size_t)B * 4);
-    h2d(d_coef, model->coef, MFS_ND_ROWS * DD * 8);
-    h2d(d_lik, model->lik, model->n_lik * 8);
-    h2d(d_inds, inds, 3 * S * S * 4);
     h2d(d_m0, m0, nb * Z * 8);
     if (mean0) h2d(d_mean0, mean0, nb * 2 * 8);
     if (scale0 && mode == MFS_MODE_SCALED) h2d(d_scale0, scale0, nb * 2 * 8);
     h2d(d_ys, ys, (size_t)B * T * 8);
     if (e == hipSuccess) {
-        mfs::FilterNdArgs a;
-        memset(&a, 0, sizeof(a));
-        a.mode = mode; a.T = T; a.B = B; a.stable = stable;
-        a.n_terms_used = model->n_terms; a.D = model->extent;
-        a.lik_kind = model->lik_kind; a.n_lik = model->n_lik; a.lik_component = model->lik_component;
-        for (int k = 0; k < MFS_ND_ROWS; ++k) {  // true extents of each Q_kappa block (trailing zero rows / columns cut)
-            int ea = 0, eb = 0;
-            for (int i = 0; i < model->extent; ++i)
-                for (int j = 0; j < model->extent; ++j)
-                    if (model->coef[(size_t)k * DD + i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
-            a.ext[k] = (ea == 0) ? 0 : (ea | (eb << 8));
-        }
-        a.coef = d_coef; a.lik = d_lik; a.inds = d_inds; a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0;
-        a.ys = d_ys; a.out_mom = d_mom; a.out_mean = d_means; a.out_scale = d_scales; a.out_nell = d_nell; a.out_first_nan = d_fn;
-        e = (model->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : ke.launch)(a, B, s);
+        rc = mfs_plan_nd_run(plan, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn, s);
     }
-    d2h(out_moments, d_mom, (size_t)B * T * Z * 8);
-    d2h(out_means, d_means, (size_t)B * T * 2 * 8);
-    d2h(out_scales, d_scales, (size_t)B * T * 2 * 8);
-    d2h(out_nell, d_nell, (size_t)B * 8);
-    d2h(out_first_nan, d_fn, (size_t)B * 4);
+    if (rc == MFS_OK) {
+        d2h(out_moments, d_mom, (size_t)B * T * Z * 8);
+        d2h(out_means, d_means, (size_t)B * T * 2 * 8);
+        d2h(out_scales, d_scales, (size_t)B * T * 2 * 8);
+        d2h(out_nell, d_nell, (size_t)B * 8);
+        d2h(out_first_nan, d_fn, (size_t)B * 4);
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d_coef); hipFree(d_lik); hipFree(d_inds); hipFree(d_m0); hipFree(d_mean0); hipFree(d_ys); hipFree(d_mom);
-    hipFree(d_means); hipFree(d_nell); hipFree(d_fn); hipFree(d_scale0); hipFree(d_scales);
+    hipFree(d_m0); hipFree(d_mean0); hipFree(d_ys); hipFree(d_mom); hipFree(d_means); hipFree(d_nell); hipFree(d_fn);
+    hipFree(d_scale0); hipFree(d_scales);
+    if (rc != MFS_OK) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
     return MFS_OK;
 }

@@ -78,9 +78,10 @@ struct NdTile {
     static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
     static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] node weights
     static constexpr int oLam = oW + ((R + 1) & ~1); // [2][NP]
-    static constexpr int RW = Z + 6;                 // per-wave reduction row: moments, flag, 5 scalar sums
-    static constexpr int oRed = oLam + 2 * NP;       // [4 waves][RW]
-    static constexpr int oCoef = oRed + 4 * RW;      // [kNdRows][D][D]
+    static constexpr int ZB = (Z + 15) / 16;         // batches of 16 moments in the transposing reduction
+    static constexpr int RW = 16 * ZB + 6;           // reduction row: moments (padded), flag, 5 scalar sums
+    static constexpr int oRed = oLam + 2 * NP;       // [4 waves x 4 DPP rows][RW]
+    static constexpr int oCoef = oRed + 16 * RW;     // [kNdRows][D][D]
     static constexpr int oMisc = oCoef + kNdRows * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
     static constexpr int kDoubles = oMisc + 8;
 };
@@ -99,6 +100,33 @@ __device__ __forceinline__ double wave_sum64(double v) {
         tot += __hiloint2double(hi, lo);
     }
     return tot;
+}
+
+// Transposing reduction of 16 values per lane across each 16-lane DPP row: at every step a lane keeps one value of a
+// pair and sends the other to its partner, so after four steps it holds ONE of the 16 values summed over its row --
+// value number bitrev4(lane & 15).  ~7 instructions per pair, 15 pairs, against 16 x (4 DPP steps + 4 readlane pairs)
+// for value-at-a-time wave sums.  Partners (row_mirror, row_half_mirror, quad [3,2,1,0], quad [1,0,3,2]) are chosen so
+// that the two lanes of a pair always hold the same subset of values.
+__device__ __forceinline__ double row_reduce16(const double (&b)[16], const int lane) {
+    const bool s3 = (lane & 8) != 0, s2 = (lane & 4) != 0, s1 = (lane & 2) != 0, s0 = (lane & 1) != 0;
+    double r1[8], r2[4], r3[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double keep = s3 ? b[2 * k + 1] : b[2 * k], send = s3 ? b[2 * k] : b[2 * k + 1];
+        r1[k] = keep + dpp_move<0x140>(send);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double keep = s2 ? r1[2 * k + 1] : r1[2 * k], send = s2 ? r1[2 * k] : r1[2 * k + 1];
+        r2[k] = keep + dpp_move<0x141>(send);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double keep = s1 ? r2[2 * k + 1] : r2[2 * k], send = s1 ? r2[2 * k] : r2[2 * k + 1];
+        r3[k] = keep + dpp_move<0x1B>(send);
+    }
+    const double keep = s0 ? r3[1] : r3[0], send = s0 ? r3[0] : r3[1];
+    return keep + dpp_move<0xB1>(send);
 }
 
 __device__ __forceinline__ double poly2d(const double* __restrict__ c, const int D, const int ext, const double x0,
@@ -452,9 +480,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
 
 // TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
 template <int N, int TK>
-__global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
+__global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N>;
-    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R, RW = L::RW;
+    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R, RW = L::RW, ZB = L::ZB;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const bool scaled = a.mode == MFS_MODE_SCALED;
@@ -476,7 +504,7 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
     if (a.mode != MFS_MODE_RAW) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
     if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
     double* red = Sm + L::oRed;
-    if (tid == 0) red[Z] = 0.0;
+    if (tid == 0) red[16 * ZB] = 0.0;
     __syncthreads();
     int first_nan = -1;
     bool dead = false;
@@ -525,15 +553,18 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 s0 = wave_sum64(s0); s1 = wave_sum64(s1); s4 = wave_sum64(s4);
                 if (scaled && half == 0) { s2 = wave_sum64(s2); s3 = wave_sum64(s3); }
                 if ((tid & 63) == 0) {
-                    double* r3 = red + RW * (tid >> 6);
-                    r3[Z + 1] = s0; r3[Z + 2] = s1; r3[Z + 3] = s4; r3[Z + 4] = s2; r3[Z + 5] = s3;
+                    double* r3 = red + 4 * RW * (tid >> 6) + 16 * ZB;
+                    r3[1] = s0; r3[2] = s1; r3[3] = s4; r3[4] = s2; r3[5] = s3;
                 }
                 __syncthreads();
-                s0 = red[Z + 1] + red[RW + Z + 1] + red[2 * RW + Z + 1] + red[3 * RW + Z + 1];
-                s1 = red[Z + 2] + red[RW + Z + 2] + red[2 * RW + Z + 2] + red[3 * RW + Z + 2];
-                s4 = red[Z + 3] + red[RW + Z + 3] + red[2 * RW + Z + 3] + red[3 * RW + Z + 3];
-                s2 = red[Z + 4] + red[RW + Z + 4] + red[2 * RW + Z + 4] + red[3 * RW + Z + 4];
-                s3 = red[Z + 5] + red[RW + Z + 5] + red[2 * RW + Z + 5] + red[3 * RW + Z + 5];
+                {
+                    const double* q = red + 16 * ZB;
+                    s0 = q[1] + q[4 * RW + 1] + q[8 * RW + 1] + q[12 * RW + 1];
+                    s1 = q[2] + q[4 * RW + 2] + q[8 * RW + 2] + q[12 * RW + 2];
+                    s4 = q[3] + q[4 * RW + 3] + q[8 * RW + 3] + q[12 * RW + 3];
+                    s2 = q[4] + q[4 * RW + 4] + q[8 * RW + 4] + q[12 * RW + 4];
+                    s3 = q[5] + q[4 * RW + 5] + q[8 * RW + 5] + q[12 * RW + 5];
+                }
                 double c0 = 0.0, c1 = 0.0, py = 1.0;
                 if (half == 0) {
                     if (a.mode != MFS_MODE_RAW) { c0 = s0; c1 = s1; }
@@ -543,127 +574,148 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                     nell -= log(py);
                 }
                 ND_STAMP(6);
-                // ---- pass 2: every moment about the new centre.  Each thread owns up to two nodes per sweep of the
-                //      node list; for each moment (compile-time multi-index) the two contributions are added and
-                //      reduced across the wave at once, so no per-thread accumulator array exists (it would spill).
-                if (TK == 1 && half == 0) {
+                // ---- pass 2: every moment about the new centre.  One node per thread per sweep of the node list; the
+                //      per-node integrands are formed 16 moments at a time (compile-time multi-indices) and each batch
+                //      goes through the transposing row reduction, after which every lane owns one moment summed over
+                //      its 16-lane row and adds it to its slot of the [16 rows][moments] LDS table -- no per-thread
+                //      accumulator array (it would spill) and no value-at-a-time wave sums.
+                const int lane16 = tid & 15;
+                const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
+                double* myred = red + (tid >> 4) * RW + cls;
+                const bool gauss_pred = (TK == 1) && (half == 0);
+                if (gauss_pred) {
                     // Normal closure: per node, E[(X'_0-c_0)^a (X'_1-c_1)^b] for a + b <= 2N-1 by the Stein recursion
                     //   M(0,b) = m_1 M(0,b-1) + (b-1) S_11 M(0,b-2)
                     //   M(a,b) = m_0 M(a-1,b) + (a-1) S_00 M(a-2,b) + b S_01 M(a-1,b-1)
-                    // (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), mfs/multi_dims/moments.py:110-154), three
-                    // rows of the table live at a time; every entry goes straight into the wave reduction.
-                    for (int base = 0; base < R; base += 512) {
-                        double wA, wB, mA0, mA1, sA00, sA01, sA11, mB0, mB1, sB00, sB01, sB11;
+                    // (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), mfs/multi_dims/moments.py:110-154); three
+                    // rows of the table live at a time.  Entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b.
+                    for (int base = 0; base < R; base += 256) {
+                        double wA, mA0, mA1, sA00, sA01, sA11;
                         {
-                            const int eA = base + tid, eB = base + 256 + tid;
-                            const bool okA = eA < R, okB = eB < R;
+                            const int eA = base + tid;
+                            const bool okA = eA < R;
                             const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
-                            const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
                             wA = okA ? W[eA] : 0.0;
-                            wB = okB ? W[eB] : 0.0;
                             const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
-                            const double xB0 = fma(lam[iB0], qs0, qm0), xB1 = fma(lam[NP + iB1], qs1, qm1);
                             mA0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xA0, xA1) - c0;
                             mA1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xA0, xA1) - c1;
                             sA00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xA0, xA1);
                             sA01 = poly2d(coef + 3 * DD, a.D, a.ext[3], xA0, xA1);
                             sA11 = poly2d(coef + 4 * DD, a.D, a.ext[4], xA0, xA1);
-                            mB0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xB0, xB1) - c0;
-                            mB1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xB0, xB1) - c1;
-                            sB00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xB0, xB1);
-                            sB01 = poly2d(coef + 3 * DD, a.D, a.ext[3], xB0, xB1);
-                            sB11 = poly2d(coef + 4 * DD, a.D, a.ext[4], xB0, xB1);
                         }
-                        double MA[3][P], MB[3][P];
-#pragma unroll
-                        for (int n0 = 0; n0 < P; ++n0) {
-                            const int r = n0 % 3, r1 = (n0 + 2) % 3, r2 = (n0 + 1) % 3;   // rows n0, n0-1, n0-2
-#pragma unroll
-                            for (int n1 = 0; n1 < P - n0; ++n1) {
-                                double vA, vB;
-                                if (n0 == 0) {
-                                    if (n1 == 0) { vA = 1.0; vB = 1.0; }
+                        double MA[3][P], bt[16];
+                        static_for<0, P>([&](auto N0c) {
+                            constexpr int n0 = N0c, r = n0 % 3, r1 = (n0 + 2) % 3, r2 = (n0 + 1) % 3;   // rows n0, n0-1, n0-2
+                            static_for<0, P - n0>([&](auto N1c) {
+                                constexpr int n1 = N1c;
+                                double vA;
+                                if constexpr (n0 == 0) {
+                                    if constexpr (n1 == 0) vA = 1.0;
                                     else {
-                                        vA = mA1 * MA[0][n1 - 1]; vB = mB1 * MB[0][n1 - 1];
-                                        if (n1 >= 2) {
-                                            vA = fma((double)(n1 - 1) * sA11, MA[0][n1 - 2], vA);
-                                            vB = fma((double)(n1 - 1) * sB11, MB[0][n1 - 2], vB);
-                                        }
+                                        vA = mA1 * MA[0][n1 > 0 ? n1 - 1 : 0];
+                                        if constexpr (n1 >= 2) vA = fma((double)(n1 - 1) * sA11, MA[0][n1 - 2], vA);
                                     }
                                 } else {
-                                    vA = mA0 * MA[r1][n1]; vB = mB0 * MB[r1][n1];
-                                    if (n0 >= 2) {
-                                        vA = fma((double)(n0 - 1) * sA00, MA[r2][n1], vA);
-                                        vB = fma((double)(n0 - 1) * sB00, MB[r2][n1], vB);
-                                    }
-                                    if (n1 >= 1) {
-                                        vA = fma((double)n1 * sA01, MA[r1][n1 - 1], vA);
-                                        vB = fma((double)n1 * sB01, MB[r1][n1 - 1], vB);
-                                    }
+                                    vA = mA0 * MA[r1][n1];
+                                    if constexpr (n0 >= 2) vA = fma((double)(n0 - 1) * sA00, MA[r2][n1], vA);
+                                    if constexpr (n1 >= 1) vA = fma((double)n1 * sA01, MA[r1][n1 - 1], vA);
                                 }
-                                MA[r][n1] = vA; MB[r][n1] = vB;
-                                const int sdeg = n0 + n1, zi = sdeg * (sdeg + 1) / 2 + n0;
-                                const double v = wave_sum64(fma(wA, vA, wB * vB));
-                                if ((tid & 63) == 0) {
-                                    double* slot = red + (tid >> 6) * RW + zi;
+                                MA[r][n1] = vA;
+                                constexpr int e = n0 * P - n0 * (n0 - 1) / 2 + n1;
+                                bt[e % 16] = wA * vA;
+                                if constexpr (e % 16 == 15 || e == Z - 1) {
+                                    if constexpr (e % 16 != 15) static_for<e % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
+                                    const double v = row_reduce16(bt, lane16);
+                                    double* slot = myred + 16 * (e / 16);
                                     *slot = (base == 0) ? v : *slot + v;
                                 }
-                            }
-                        }
+                            });
+                        });
                     }
-                } else
-                for (int base = 0; base < R; base += 512) {
-                    double wA, wB, pxA0[P], pxA1[P], pxB0[P], pxB1[P], QA[kNdTerms], QB[kNdTerms];
-                    {
-                        const int eA = base + tid, eB = base + 256 + tid;
-                        const bool okA = eA < R, okB = eB < R;
-                        const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
-                        const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
-                        wA = okA ? W[eA] : 0.0;
-                        wB = okB ? W[eB] : 0.0;
-                        const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
-                        const double xB0 = fma(lam[iB0], qs0, qm0), xB1 = fma(lam[NP + iB1], qs1, qm1);
-                        pxA0[0] = pxA1[0] = pxB0[0] = pxB1[0] = 1.0;
+                } else if (TK == 0 && half == 0) {
+                    // Operator-table prediction: f_n(x) = sum_kappa Q_kappa(x) d^kappa (x - c)^n factorises over the two
+                    // coordinates,  f_n = sum_{k0 <= 4} [n0!/(n0-k0)! dx0^(n0-k0)] g_{k0}(n1),
+                    //               g_{k0}(n1) = sum_{k1 <= 4-k0} Q_(k0,k1) n1!/(n1-k1)! dx1^(n1-k1)   (Q_(0,0) = 1),
+                    // so a column of moments sharing n1 costs 15 FMAs once plus 5 per moment instead of 15 per moment.
+                    // Entries are emitted column by column: slot e(n1, n0) = n1 P - n1(n1-1)/2 + n0.
+                    for (int base = 0; base < R; base += 256) {
+                        double wA, pxA0[P], pxA1[P], QA[kNdTerms + 1], bt[16];
+                        {
+                            const int eA = base + tid;
+                            const bool okA = eA < R;
+                            const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
+                            wA = okA ? W[eA] : 0.0;
+                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
+                            pxA0[0] = pxA1[0] = 1.0;
 #pragma unroll
-                        for (int p = 1; p < P; ++p) {
-                            pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1);
-                            pxB0[p] = pxB0[p - 1] * (xB0 - c0); pxB1[p] = pxB1[p - 1] * (xB1 - c1);
+                            for (int p = 1; p < P; ++p) { pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1); }
+                            QA[0] = 1.0;   // kappa = (0, 0)
+#pragma unroll
+                            for (int k = 0; k < kNdTerms; ++k)
+                                QA[k + 1] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xA0, xA1) : 0.0;
                         }
-                        if (TK == 0 && half == 0) {
-#pragma unroll
-                            for (int k = 0; k < kNdTerms; ++k) {
-                                QA[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xA0, xA1) : 0.0;
-                                QB[k] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xB0, xB1) : 0.0;
-                            }
-                        } else {
-                            wA *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
-                            wB *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xB0 : xB1);
-#pragma unroll
-                            for (int k = 0; k < kNdTerms; ++k) { QA[k] = 0.0; QB[k] = 0.0; }
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2 * N; ++s) {
-#pragma unroll
-                        for (int n0 = 0; n0 <= s; ++n0) {
-                            const int n1 = s - n0, zi = s * (s + 1) / 2 + n0;
-                            double vA = pxA0[n0] * pxA1[n1], vB = pxB0[n0] * pxB1[n1];
-                            if (TK == 0 && half == 0) {
-#pragma unroll
-                                for (int k = 0; k < kNdTerms; ++k) {
-                                    if (kKap0[k] <= n0 && kKap1[k] <= n1) {
-                                        const double ff = ffact(n0, kKap0[k]) * ffact(n1, kKap1[k]);
-                                        vA = fma(QA[k] * ff, pxA0[n0 - kKap0[k]] * pxA1[n1 - kKap1[k]], vA);
-                                        vB = fma(QB[k] * ff, pxB0[n0 - kKap0[k]] * pxB1[n1 - kKap1[k]], vB);
-                                    }
+                        static_for<0, P>([&](auto N1c) {
+                            constexpr int n1 = N1c;
+                            double t1[5], g[5];
+                            static_for<0, 5>([&](auto K1c) {
+                                constexpr int k1 = K1c;
+                                if constexpr (k1 <= n1) t1[k1] = ffact(n1, k1) * pxA1[n1 - k1];
+                            });
+                            static_for<0, 5>([&](auto K0c) {
+                                constexpr int k0 = K0c;
+                                double acc = 0.0;
+                                static_for<0, 5 - k0>([&](auto K1c) {
+                                    constexpr int k1 = K1c, sk = k0 + k1;
+                                    if constexpr (k1 <= n1) acc = fma(QA[sk * (sk + 1) / 2 + k0], t1[k1], acc);  // (0,0) -> slot 0
+                                });
+                                g[k0] = acc;
+                            });
+                            static_for<0, P - n1>([&](auto N0c) {
+                                constexpr int n0 = N0c;
+                                double vA = g[0] * pxA0[n0];
+                                static_for<1, 5>([&](auto K0c) {
+                                    constexpr int k0 = K0c;
+                                    if constexpr (k0 <= n0) vA = fma(g[k0] * ffact(n0, k0), pxA0[n0 - k0], vA);
+                                });
+                                constexpr int e = n1 * P - n1 * (n1 - 1) / 2 + n0;
+                                bt[e % 16] = wA * vA;
+                                if constexpr (e % 16 == 15 || e == Z - 1) {
+                                    if constexpr (e % 16 != 15) static_for<e % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
+                                    const double v = row_reduce16(bt, lane16);
+                                    double* slot = myred + 16 * (e / 16);
+                                    *slot = (base == 0) ? v : *slot + v;
                                 }
-                            }
-                            const double v = wave_sum64(fma(wA, vA, wB * vB));
-                            if ((tid & 63) == 0) {
-                                double* slot = red + (tid >> 6) * RW + zi;
-                                *slot = (base == 0) ? v : *slot + v;
-                            }
+                            });
+                        });
+                    }
+                } else {
+                    // update (either transition kind): prod_k (x_k - c_k)^{n_k} times the likelihood, in table order
+                    for (int base = 0; base < R; base += 256) {
+                        double wA, pxA0[P], pxA1[P], bt[16];
+                        {
+                            const int eA = base + tid;
+                            const bool okA = eA < R;
+                            const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
+                            wA = okA ? W[eA] : 0.0;
+                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
+                            pxA0[0] = pxA1[0] = 1.0;
+#pragma unroll
+                            for (int p = 1; p < P; ++p) { pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1); }
+                            wA *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
                         }
+                        static_for<0, 2 * N>([&](auto Sc) {
+                            constexpr int sd = Sc;
+                            static_for<0, sd + 1>([&](auto N0c) {
+                                constexpr int n0 = N0c, n1 = sd - n0, zi = sd * (sd + 1) / 2 + n0;
+                                bt[zi % 16] = wA * (pxA0[n0] * pxA1[n1]);
+                                if constexpr (zi % 16 == 15 || zi == Z - 1) {
+                                    if constexpr (zi % 16 != 15) static_for<zi % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
+                                    const double v = row_reduce16(bt, lane16);
+                                    double* slot = myred + 16 * (zi / 16);
+                                    *slot = (base == 0) ? v : *slot + v;
+                                }
+                            });
+                        });
                     }
                 }
                 __syncthreads();
@@ -676,17 +728,25 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                 if (scaled) {
                     if (half == 0) { ns0 = sqrt(s2); ns1 = sqrt(s3); }
                     else {
-                        ns0 = sqrt((red[5] + red[RW + 5] + red[2 * RW + 5] + red[3 * RW + 5]) * ipy);   // (2, 0)
-                        ns1 = sqrt((red[3] + red[RW + 3] + red[2 * RW + 3] + red[3 * RW + 3]) * ipy);   // (0, 2)
+                        double v5 = 0.0, v3 = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) { v5 += red[q * RW + 5]; v3 += red[q * RW + 3]; }
+                        ns0 = sqrt(v5 * ipy);   // (2, 0)
+                        ns1 = sqrt(v3 * ipy);   // (0, 2)
                     }
                 }
                 for (int zi = tid; zi < Z; zi += 256) {
-                    double v = red[zi] + red[RW + zi] + red[2 * RW + zi] + red[3 * RW + zi];
+                    int sd = 0;
+                    while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                    const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                    // where pass 2 left this moment: predictions emit row by row (Normal closure) or column by column
+                    const int e = (half != 0) ? zi : (TK == 1) ? n0 * P - n0 * (n0 - 1) / 2 + n1
+                                                              : n1 * P - n1 * (n1 - 1) / 2 + n0;
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v += red[q * RW + e];
                     v = (half == 0) ? v : v * ipy;
                     if (scaled) {
-                        int sd = 0;
-                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
                         const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
                         double f = 1.0;
                         for (int q = 0; q < n0; ++q) f *= i0;
@@ -694,14 +754,14 @@ __global__ __launch_bounds__(256) void filternd_kernel(const FilterNdArgs a) {
                         v *= f;
                     }
                     mom[zi] = v;
-                    if (!finite(v)) red[Z] = 1.0;  // slot Z of the first row flags a non-finite moment
+                    if (!finite(v)) red[16 * ZB] = 1.0;  // slot Z of the first row flags a non-finite moment
                 }
                 if (a.mode != MFS_MODE_RAW) { mean0 = c0; mean1 = c1; }
                 if (scaled) { scale0 = ns0; scale1 = ns1; }
                 __syncthreads();
-                bad = bad || poisoned || (red[Z] != 0.0);
+                bad = bad || poisoned || (red[16 * ZB] != 0.0);
                 __syncthreads();
-                if (tid == 0) red[Z] = 0.0;
+                if (tid == 0) red[16 * ZB] = 0.0;
                 ND_STAMP(7);
 #ifdef MFS_ND_STAMPS
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
