@@ -358,15 +358,20 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 int p, q;
                 tournament_pair<NP>(r, P, p, q);
                 const double app = Kk[p * LD + p], aqq = Kk[q * LD + q], apq = Kk[p * LD + q];
+                // t = tan of the Jacobi angle = 2 a_pq / (d + sgn(d) sqrt(d^2 + 4 a_pq^2)), d = a_qq - a_pp, through
+                // reciprocal / reciprocal-square-root seeds: t only decides how well a_pq is annihilated (one Newton
+                // step is plenty), c = (1 + t^2)^-1/2 decides the orthogonality of V and gets two.
+                const double d = aqq - app, h = apq + apq;
+                const double rr = fma(d, d, h * h);
                 double c = 1.0, s = 0.0, t = 0.0;
-                if (apq != 0.0) {
-                    // the rotation through reciprocal / reciprocal-square-root seeds + Newton steps: a third of the
-                    // latency of full-precision divides and square roots, on the critical path of every round
-                    const double theta = (aqq - app) * rcp_nr(2.0 * apq);
-                    const double v = fma(theta, theta, 1.0);
-                    const double root = v * rsq_nr(v);                       // sqrt(theta^2 + 1); inf stays inf
-                    t = copysign(rcp_nr(fabs(theta) + root), theta);
-                    t = finite(root) ? t : 0.0;                               // |theta| huge: no rotation needed
+                if (apq != 0.0 && rr > 0.0) {
+                    double y = __builtin_amdgcn_rsq(rr);
+                    y = fma(y, fma(-0.5 * rr * y, y, 0.5), y);
+                    const double den = d + copysign(rr * y, d);
+                    double z = __builtin_amdgcn_rcp(den);
+                    z = fma(fma(-den, z, 1.0), z, z);
+                    t = h * z;
+                    t = finite(t) ? t : 0.0;
                     c = rsq_nr(fma(t, t, 1.0));
                     s = t * c;
                 }
