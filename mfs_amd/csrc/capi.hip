@@ -221,7 +221,7 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     alloc((void**)&p->c_scale, (size_t)B * 8);
     alloc((void**)&p->c_nell, (size_t)B * 8);
     alloc((void**)&p->c_first_nan, (size_t)B * 4);
-    if (p->chunk < T && slot >= 3) alloc((void**)&p->c_lam, (size_t)B * 2 * p->G * 8);
+    if (p->chunk < T && slot >= 3) alloc((void**)&p->c_lam, (size_t)B * p->G * 8);
     if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, ncoef * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, nlik * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);

@@ -213,27 +213,30 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     static_for<0, N>([&](auto J) { g[J] = mom[li + J]; });
 
     F1_STAMP(0);
-    // -- Cholesky, row per lane, left-looking by column (quadtures.py:127); L[j][k] reaches the other lanes by DPP
-    double Lr[N];
+    // -- Cholesky, row per lane, left-looking by column (quadtures.py:127), kept in its square-root-free form: only the
+    //    pivots d_j = L_jj^2 and the sub-diagonal enter the Jacobi matrix below, and L_ik L_jk = u_ik u_jk / d_k with the
+    //    unnormalised columns u, so no square root is ever taken.  u_jk / d_k reaches the other lanes by DPP.
+    double Ur[N], Vr[N];             // u_lk and u_lk / d_k of this lane's row
     double piv[N], sub[N], ipiv[N];  // group-uniform
     bool poisoned = false;
     static_for<0, N>([&](auto Jc) {
         constexpr int j = Jc;
-        double s = g[j];
+        double s = g[j], s2 = 0.0;   // two partial sums: the dot product is not one dependent chain
         static_for<0, j>([&](auto Kc) {
             constexpr int k = Kc;
-            s = fma(-Lr[k], bcast<G, j>(Lr[k]), s);
+            if constexpr ((j - 1 - k) % 2 == 0) s = fma(-Ur[k], bcast<G, j>(Vr[k]), s);   // k = j - 1 (the late one) lands here
+            else s2 = fma(-Ur[k], bcast<G, j>(Vr[k]), s2);
         });
+        if constexpr (j >= 2) s += s2;
         const double pj = bcast<G, j>(s);
         piv[j] = pj;
         sub[j] = bcast<G, j + 1>(s);
         poisoned |= !(pj > 0.0);
-        // 1/sqrt(piv): hardware v_rsq_f64 seed (only ~1e-7 relative) + two Newton-Raphson steps -> ~1e-16
-        const double y0 = __builtin_amdgcn_rsq(pj);
-        const double y1 = fma(y0, fma(-0.5 * pj * y0, y0, 0.5), y0);
-        const double rinv = fma(y1, fma(-0.5 * pj * y1, y1, 0.5), y1);
-        ipiv[j] = rinv * rinv;
-        Lr[j] = s * rinv;
+        // 1 / pivot: hardware v_rcp_f64 seed + two Newton-Raphson steps -> ~1e-16
+        const double ip = rcp_nr(pj);
+        ipiv[j] = ip;
+        Ur[j] = s;
+        Vr[j] = s * ip;
     });
 
     F1_STAMP(1);
@@ -280,33 +283,37 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 #ifdef MFS_1D_STAMPS
             if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[10] += 1;
 #endif
+            // p, p' and h = p''/2 by the three-term recurrence (h_n = t h_{n-1} - b^2 h_{n-2} - p'_{n-1})
             double p0 = 1.0, p1 = a[0] - x, d0 = 0.0, d1 = -1.0, e0 = 0.0, e1 = 0.0;
-            // Sturm count = number of sign changes along p_0..p_N, taken from the sign bits with integer VALU ops
-            // (a floating-point compare per step would bounce through SGPR masks next to the recurrence's chain)
-            unsigned sgn = (unsigned)__double2hiint(p1) >> 31;
-            int cnt = (int)sgn;                            // p_0 = 1 > 0: a negative p_1 is the first change
+            // Sturm count = number of sign changes along p_0..p_N.  The sign bits are shifted into one word as the
+            // recurrence runs (one v_alignbit per step; floating-point compares would bounce through SGPR masks next
+            // to the chain) and the changes are counted at the end.  p_0 = 1 > 0 is the zero bit above the first one.
+            unsigned signs = (unsigned)__double2hiint(p1) >> 31;
             static_for<1, N>([&](auto Jc) {
                 constexpr int j = Jc;
                 const double t = a[j] - x;
                 const double pn = fma(t, p1, -b2[j - 1] * p0);
                 const double dn = fma(t, d1, fma(-b2[j - 1], d0, -p1));
-                const double en = fma(t, e1, fma(-b2[j - 1], e0, -2.0 * d1));
-                const unsigned sn = (unsigned)__double2hiint(pn) >> 31;
-                cnt += (int)(sn ^ sgn);
-                sgn = sn;
+                const double en = fma(t, e1, fma(-b2[j - 1], e0, -d1));
+                signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(pn), 31);
                 p0 = p1; p1 = pn; d0 = d1; d1 = dn; e0 = e1; e1 = en;
             });
+            const int cnt = __popc(signs ^ (signs >> 1));
             if (!conv) {  // a converged lane is frozen
                 if (cnt <= k) lo = x; else hi = x;
                 const double mid = 0.5 * (lo + hi);
                 // S = sqrt((N-1) ((N-1) p'^2 - N p p'')) >= 0 for real-rooted p (clamped against rounding)
                 // (the step only has to be accurate enough to converge: seeds + Newton steps instead of full-precision
                 //  sqrt / divide; the accuracy of the root comes from the recurrence evaluation, not from the step)
-                const double disc = fmax((double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)N * p1 * e1), 0.0);
-                const double S = copysign(disc > 0.0 ? disc * rsq_nr(disc) : 0.0, p1);
+                const double disc = fmax((double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)(2 * N) * p1 * e1), 0.0);
+                double rs = __builtin_amdgcn_rsq(disc);
+                rs = fma(rs, fma(-0.5 * disc * rs, rs, 0.5), rs);          // one Newton step each: ~1e-14 on the step
+                const double S = copysign(disc > 0.0 ? disc * rs : 0.0, p1);
                 const bool right = (cnt == k), left = (cnt == k + 1);
                 const double den = right ? (d1 - S) : (d1 + S);
-                double xn = x - (double)N * p1 * rcp_nr(den);
+                double rd = __builtin_amdgcn_rcp(den);
+                rd = fma(fma(-den, rd, 1.0), rd, rd);
+                double xn = x - (double)N * p1 * rd;
                 const bool ok = (right && xn >= x && xn < hi) || (left && xn <= x && xn > lo);  // false for NaN
                 xn = ok ? xn : mid;
                 // Laguerre converges cubically near its root: e_next ~ e^3 / gap^2 with gap >~ W / N, so a step below
@@ -390,9 +397,13 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
     bool dead = (first_nan >= 0);
     const double qnan = __builtin_nan("");
     const bool node = (l < N);
-    // warm starts for the predict / update quadratures; part of the carry so that a chunked run is bit-identical
-    double lamA = qnan, lamB = qnan;
-    if (a.t_begin != 0 && a.c_lam) { lamA = a.c_lam[((size_t)b * 2) * G + l]; lamB = a.c_lam[((size_t)b * 2 + 1) * G + l]; }
+    // Warm start of the eigenvalue iterations: every rule starts from the rule found just before it (the update-half
+    // rule of step t-1 for the predict half of step t, that one for the update half).  Measured against starting each
+    // half from its own predecessor, and against extrapolating the shift of the previous prediction / update, this
+    // needs the fewest Laguerre iterations for the slowest lane of the wave.  A start only steers the iteration, never
+    // the result; the last rule is part of the carry so that a chunked run is bit-identical.
+    double lamB = qnan;
+    if (a.t_begin != 0 && a.c_lam) lamB = a.c_lam[(size_t)b * G + l];
     double ywin = 0.0;                  // window of measurements (16 steps, or G when G < 16), one per lane
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
@@ -403,10 +414,12 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
         const double y = __shfl(ywin, tw, YW);
         if (!dead) {
             int bad = 0;
+            double lamA = qnan;
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
                 double x, w;
-                double lam_io = (half == 0) ? lamA : lamB;
+                double lam_io;
+                if (half == 0) lam_io = lamB; else lam_io = lamA;
                 quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w, lam_io);
                 if (half == 0) lamA = lam_io; else lamB = lam_io;
                 F1_STAMP_BEGIN;
@@ -528,7 +541,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
         }
     } else {
         for (int n = l; n < M2; n += G) a.c_mom[(size_t)b * M2 + n] = mom[n];
-        if (a.c_lam) { a.c_lam[((size_t)b * 2) * G + l] = lamA; a.c_lam[((size_t)b * 2 + 1) * G + l] = lamB; }
+        if (a.c_lam) a.c_lam[(size_t)b * G + l] = lamB;
         if (l == 0) {
             a.c_mean[b] = mean; a.c_scale[b] = scale; a.c_nell[b] = nell; a.c_first_nan[b] = first_nan;
         }
