@@ -44,7 +44,7 @@ struct Filter1dArgs {
     double* c_scale;
     double* c_nell;
     int32_t* c_first_nan;
-    double* c_lam;  // [B][G] eigenvalue warm start: the last update-half rule (fast path, chunked runs only)
+    double* c_lam;  // [B][G] pending eigenvalue warm start of the next predict half (fast path, chunked runs only)
     // outputs (any may be null except out_nell)
     double* out_mom;
     double* out_mean;

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 from mfs_amd import _lib, synth
 _lib.LIB_PATH = os.path.abspath('tools/diag/libmfs_stamps.so')
 from mfs_amd.one_dim import filtering, moments, ss_models
-N, T, B = 15, 200, 64
+N, T, B = 15, int(os.environ.get('STAMP_T', '200')), 64
 dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
 _, c, _, mu, _ = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
 ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=100)
@@ -13,6 +13,7 @@ L = _lib.lib(); L.mfs_debug_stamps.argtypes = [C.c_void_p]; print('rc', L.mfs_de
 st = np.array(list(st), dtype=np.float64)
 names = ['hankel gather', 'cholesky', 'jacobi coeffs', 'laguerre', 'weights', 'predict contributions', 'update contributions', 'moment reduction']
 halves = st[9]
+print('iterations per quadrature: predict half', st[11] / (st[9] / 2), 'update half', st[12] / (st[9] / 2))
 print('filter 0 first_nan', fn[0], 'half-steps', halves, 'laguerre iterations per quadrature', st[10] / halves)
 tot = st[:8].sum()
 for i, n in enumerate(names):
