@@ -310,28 +310,30 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                 p0 = p1; p1 = pn; d0 = d1; d1 = dn; e0 = e1; e1 = en;
             });
             const int cnt = __popc(signs ^ (signs >> 1));
-            if (!conv) {  // a converged lane is frozen
-                if (cnt <= k) lo = x; else hi = x;
-                const double mid = 0.5 * (lo + hi);
+            {   // straight-line and predicated (bitwise, not short-circuit, logic: no divergent branches in the loop);
+                // a converged lane is frozen by the selects at the end
+                const bool below = cnt <= k;
+                const double lo_n = below ? x : lo, hi_n = below ? hi : x;
+                const double mid = 0.5 * (lo_n + hi_n);
                 // S = sqrt((N-1) ((N-1) p'^2 - N p p'')) >= 0 for real-rooted p (clamped against rounding)
-                // (the step only has to be accurate enough to converge: seeds + Newton steps instead of full-precision
-                //  sqrt / divide; the accuracy of the root comes from the recurrence evaluation, not from the step)
+                // (the step only has to be accurate enough to converge: seeds + one Newton step instead of
+                //  full-precision sqrt / divide; the accuracy of the root comes from the recurrence evaluation)
                 const double disc = fmax((double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)(2 * N) * p1 * e1), 0.0);
                 double rs = __builtin_amdgcn_rsq(disc);
-                rs = fma(rs, fma(-0.5 * disc * rs, rs, 0.5), rs);          // one Newton step each: ~1e-14 on the step
+                rs = fma(rs, fma(-0.5 * disc * rs, rs, 0.5), rs);
                 const double S = copysign(disc > 0.0 ? disc * rs : 0.0, p1);
                 const bool right = (cnt == k), left = (cnt == k + 1);
                 const double den = right ? (d1 - S) : (d1 + S);
                 double rd = __builtin_amdgcn_rcp(den);
                 rd = fma(fma(-den, rd, 1.0), rd, rd);
                 double xn = x - (double)N * p1 * rd;
-                const bool ok = (right && xn >= x && xn < hi) || (left && xn <= x && xn > lo);  // false for NaN
+                const bool ok = (right & (xn >= x) & (xn < hi_n)) | (left & (xn <= x) & (xn > lo_n));  // false for NaN
                 xn = ok ? xn : mid;
                 // Laguerre converges cubically near its root: e_next ~ e^3 / gap^2 with gap >~ W / N, so a step below
                 // 1e-6 W lands within ~N^2 1e-18 W of the root and the confirming evaluation can be skipped -- but only
                 // with evidence of that regime: a small step also occurs right after leaving the neighbourhood of a
                 // DIFFERENT root (steps then grow by ~N/(N-2) per iteration).  Hence: small AND at least 100x smaller
-                // than the previous Laguerre step of this lane.
+                // than the previous Laguerre step of this lane ...
                 const double step = fabs(xn - x);
                 // ... or with the bound that needs no history: p'/p = sum_i 1/(x - lambda_i), so when the Newton step
                 // -p/p' points the way we travel, the roots ahead dominate that sum and the nearest of them lies within
@@ -340,11 +342,14 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                 //  update-half rule -- see the kernel.)
                 const double nwt = -p1 * d1;   // sign of the Newton step -p/p'
                 const bool ahead = right ? (nwt > 0.0) : (nwt < 0.0);
-                const bool near = ok && ahead && (double)N * fabs(p1) <= (3e-7 * wscale) * fabs(d1);
-                conv = (ok && step <= tol) || (ok && step <= kLagStop * wscale && step <= 1e-2 * prev_step) || near ||
-                       (hi - lo <= tol) || (p1 == 0.0 && (right || left));
-                prev_step = ok ? step : 0.0;
-                x = xn;
+                const bool near = ok & ahead & ((double)N * fabs(p1) <= (3e-7 * wscale) * fabs(d1));
+                const bool conv_n = (ok & (step <= tol)) | (ok & (step <= kLagStop * wscale) & (step <= 1e-2 * prev_step)) |
+                                    near | (hi_n - lo_n <= tol) | ((p1 == 0.0) & (right | left));
+                lo = conv ? lo : lo_n;
+                hi = conv ? hi : hi_n;
+                prev_step = conv ? prev_step : (ok ? step : 0.0);
+                x = conv ? x : xn;
+                conv = conv | conv_n;
             }
             if (gall<G>(conv, grp)) break;
         }
@@ -538,13 +543,19 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                 F1_STAMP(5 + half);
                 wave_sync();
                 const double ipy = 1.0 / py;
-                for (int n = l; n < M2; n += G) {
-                    double acc = 0.0;
+                {   // column sums of the contribution table: each lane owns moments l and l + G (2N <= 2G - 2), summed
+                    // together in three partial sums each -- a dependent add costs several issue slots on one wave
+                    const int n0 = l, n1 = l + G;
+                    const bool has0 = n0 < M2, has1 = n1 < M2;
+                    const double* t0 = TAB + (has0 ? n0 : 0);
+                    const double* t1 = TAB + (has1 ? n1 : 0);
+                    double s0[3] = {0.0, 0.0, 0.0}, s1[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < N; ++i) acc += TAB[i * TLD + n];
-                    acc = (half == 0) ? acc : acc * ipy;
-                    mom[n] = acc;
-                    bad |= !finite(acc);
+                    for (int i = 0; i < N; ++i) { s0[i % 3] += t0[i * TLD]; s1[i % 3] += t1[i * TLD]; }
+                    double acc0 = (s0[0] + s0[1]) + s0[2], acc1 = (s1[0] + s1[1]) + s1[2];
+                    if (half != 0) { acc0 *= ipy; acc1 *= ipy; }
+                    if (has0) { mom[n0] = acc0; bad |= !finite(acc0); }
+                    if (has1) { mom[n1] = acc1; bad |= !finite(acc1); }
                 }
                 wave_sync();
                 F1_STAMP(7);
