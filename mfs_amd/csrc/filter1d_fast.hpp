@@ -114,17 +114,25 @@ __device__ __forceinline__ bool gany(bool flag, int grp) {
     return (m & want) != 0ull;
 }
 
-// acc[r] = row r of the coefficient table evaluated at u, for R rows at once: the Horner recurrences of the rows
-// advance together, so the LDS reads of one degree are in flight together instead of one latency per coefficient.
+// acc[r] = row r of the coefficient table evaluated at u, for R rows at once.  The LDS copy of the table is
+// degree-major and zero-padded to kCoefRows rows ([degree + 1][kCoefRows]): the coefficients of one degree are
+// contiguous, read unconditionally in wide LDS reads that are all in flight together, and the Horner recurrences of the
+// rows advance side by side -- no per-coefficient branch, no per-coefficient LDS latency.
+constexpr int kCoefRows = (MFS_MAX_TERMS + 1 + 1) & ~1;   // 9 rows (operator terms + variance), padded to 10
 template <int R>
-__device__ __forceinline__ void horner_rows(const double* __restrict__ table, const int n_rows, const int degree,
-                                            const double u, double (&acc)[R]) {
-    const int J1 = degree + 1;
+__device__ __forceinline__ void horner_rows(const double* __restrict__ table, const int degree, const double u,
+                                            double (&acc)[R]) {
+    static_assert(R <= kCoefRows, "table rows");
+    const double* t = table + degree * kCoefRows;
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = (r < n_rows) ? table[r * J1 + degree] : 0.0;
+    for (int r = 0; r < R; ++r) acc[r] = t[r];
     for (int j = degree - 1; j >= 0; --j) {
+        t -= kCoefRows;
+        double cj[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = (r < n_rows) ? fma(acc[r], u, table[r * J1 + j]) : 0.0;
+        for (int r = 0; r < R; ++r) cj[r] = t[r];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = fma(acc[r], u, cj[r]);
     }
 }
 
@@ -177,7 +185,7 @@ struct FastTile {
     static constexpr int TLD = M2 + 1;
     static constexpr int oLik = oTab + N * TLD;
     static constexpr int oLfac = (oLik + MFS_MAX_LIK + 1) & ~1;  // log(y!) for y = 0..kLfacMax (Poisson likelihood)
-    static constexpr int oCoef = oLfac + 34;                    // model table, n_rows * (degree + 1) doubles
+    static constexpr int oCoef = oLfac + 34;                    // model table, (degree + 1) * kCoefRows doubles
     static constexpr int fixedDoubles = oCoef;
 };
 
@@ -396,7 +404,10 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
 
     {   // stage the model tables and the carry
         const double* src = a.coef + (a.coef_batched ? (size_t)b * a.n_rows * J1 : 0);
-        for (int e = l; e < a.n_rows * J1; e += G) S[L::oCoef + e] = src[e];
+        for (int e = l; e < J1 * kCoefRows; e += G) {   // [row][degree] in HBM -> [degree][row] zero-padded in LDS
+            const int j = e / kCoefRows, r = e - j * kCoefRows;
+            S[L::oCoef + e] = (r < a.n_rows) ? src[r * J1 + j] : 0.0;
+        }
         const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
         for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + e] = (e < a.n_lik) ? ls[e] : 0.0;
         if (a.lik_kind == MFS_LIK_POISSON_SOFTPLUS)
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                     // ---- prediction (filtering.py:76-79 / 144-148 / 221-225)
                     // every row of the model table at this lane's node, in one pass over the degrees
                     double rows[MFS_MAX_TERMS + 1];
-                    horner_rows<MFS_MAX_TERMS + 1>(coef, a.n_rows, a.degree, u, rows);
+                    horner_rows<MFS_MAX_TERMS + 1>(coef, a.degree, u, rows);
                     double mu, var;
                     if (a.trans_kind == MFS_TRANS_OPERATOR) {
                         mu = x + rows[0];
