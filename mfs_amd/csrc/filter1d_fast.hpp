@@ -169,7 +169,7 @@ __device__ __forceinline__ void operator_moments(const double (&rows)[MFS_MAX_TE
             else if (k % 3 == 1) v1 = fma(Qp[k], E[k], v1);
             else v2 = fma(Qp[k], E[k], v2);
         }
-        if (node) row[n] = sc_n * ((v0 + v1) + v2);
+        row[n] = sc_n * ((v0 + v1) + v2);
         sc_n *= inv_sc;
 #pragma unroll
         for (int k = KT; k >= 1; --k) E[k] = fma(dx, E[k], E[k - 1]);
@@ -177,13 +177,13 @@ __device__ __forceinline__ void operator_moments(const double (&rows)[MFS_MAX_TE
     }
 }
 
-template <int N>
+template <int N, int G>
 struct FastTile {
     static constexpr int M2 = 2 * N;
     static constexpr int oMom = 0;             // [2N] moment vector (Hankel source)
-    static constexpr int oTab = M2;            // [N][2N + 1] per-node contributions (row padded: conflict-free)
-    static constexpr int TLD = M2 + 1;
-    static constexpr int oLik = oTab + N * TLD;
+    static constexpr int oTab = M2;            // [G][2N + 1] per-lane contributions (row padded: conflict-free); rows
+    static constexpr int TLD = M2 + 1;         // N..G-1 belong to the spare lanes, written unconditionally, never read
+    static constexpr int oLik = oTab + G * TLD;
     static constexpr int oLfac = (oLik + MFS_MAX_LIK + 1) & ~1;  // log(y!) for y = 0..kLfacMax (Poisson likelihood)
     static constexpr int oCoef = oLfac + 34;                    // model table, (degree + 1) * kCoefRows doubles
     static constexpr int fixedDoubles = oCoef;
@@ -386,7 +386,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 // ---------------------------------------------------------------------------------------------------------------
 template <int N, int G, int WPB>
 __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
-    using L = FastTile<N>;
+    using L = FastTile<N, G>;
     constexpr int M2 = L::M2, TLD = L::TLD;
     constexpr int FPW = 64 / G;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                             inv_sc = 1.0 / scale;
                         }
                     }
-                    double* row = TAB + (node ? l : 0) * TLD;
+                    double* row = TAB + l * TLD;   // spare lanes own spare rows: every store below is unconditional
                     if (a.trans_kind == MFS_TRANS_OPERATOR) {
                         // E[(X'-c)^n | x] = sum_k Q_k(u) n!/(n-k)! (x-c)^(n-k) = sum_k (k! Q_k) C(n,k) dx^(n-k);
                         // E_k(n) = C(n,k) dx^(n-k) advances in n by Pascal's rule E_k(n+1) = dx E_k(n) + E_{k-1}(n)
@@ -515,13 +515,13 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                         // normal closure: E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n-1) v E_{n-2}   (moments.py:70-74)
                         const double m = mu - c;
                         double e2 = 1.0, e1 = m, sc_n = w;
-                        if (node) row[0] = sc_n;
+                        row[0] = sc_n;
                         sc_n *= inv_sc;
-                        if (node) row[1] = sc_n * m;
+                        row[1] = sc_n * m;
                         for (int n = 2; n < M2; ++n) {
                             const double e = fma(m, e1, (double)(n - 1) * var * e2);
                             sc_n *= inv_sc;
-                            if (node) row[n] = sc_n * e;
+                            row[n] = sc_n * e;
                             e2 = e1;
                             e1 = e;
                         }
@@ -543,10 +543,11 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                         const double last = bcast<G, N - 1>(dx);
                         gA = node ? dx : last;
                     }
-                    double* row = TAB + (node ? l : 0) * TLD;
+                    double* row = TAB + l * TLD;
                     double p = wl;
+#pragma unroll
                     for (int n = 0; n < M2; ++n) {
-                        if (node) row[n] = p;
+                        row[n] = p;
                         p *= dx;
                     }
                     nell -= log(py);

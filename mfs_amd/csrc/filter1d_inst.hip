@@ -93,7 +93,7 @@ void reg_fast(int gi) {
     g_fast_filter[N][gi] = &launch_filter_fast<N, G>;
     e.filter = nullptr;
     e.quad = &launch_quad_fast<N, G>;
-    e.lds_doubles_per_filter = FastTile<N>::fixedDoubles;
+    e.lds_doubles_per_filter = FastTile<N, G>::fixedDoubles;
     e.waves_per_block = 1;
     e.lanes_per_filter = G;
 }
