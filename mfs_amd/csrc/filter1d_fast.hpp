@@ -66,6 +66,19 @@ __device__ __forceinline__ double bcast(double v) {
     }
 }
 
+// acc -= u * (v of lane J of the group).  For G = 16 the broadcast is the DPP modifier of the multiply-add itself
+// (v_fmac_f64_dpp row_newbcast: one instruction instead of v_mov_b64_dpp + v_fma_f64; the compiler does not form it).
+// s_nop 1 covers the two wait states a DPP read needs after a VALU write of its source.
+template <int G, int J>
+__device__ __forceinline__ void fnma_bcast(double& acc, const double u, const double v) {
+    if constexpr (G == 16) {
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc) : "v"(v), "v"(u), "n"(J));
+    } else {
+        acc = fma(-u, bcast<G, J>(v), acc);
+    }
+}
+
 // sum over the G lanes of the group, result in every lane.  G = 16 is one DPP row: xor-1, xor-2 inside quads,
 // then half-row mirror and row mirror -- 2 v_mov_b32_dpp + 1 v_add_f64 per stage at VALU latency instead of
 // ds_bpermute round trips through the LDS crossbar.
@@ -232,19 +245,23 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         double s = g[j], s2 = 0.0;   // two partial sums: the dot product is not one dependent chain
         static_for<0, j>([&](auto Kc) {
             constexpr int k = Kc;
-            if constexpr ((j - 1 - k) % 2 == 0) s = fma(-Ur[k], bcast<G, j>(Vr[k]), s);   // k = j - 1 (the late one) lands here
-            else s2 = fma(-Ur[k], bcast<G, j>(Vr[k]), s2);
+            if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<G, j>(s, Ur[k], Vr[k]);   // k = j - 1 (the late one) lands here
+            else fnma_bcast<G, j>(s2, Ur[k], Vr[k]);
         });
         if constexpr (j >= 2) s += s2;
         const double pj = bcast<G, j>(s);
         piv[j] = pj;
         sub[j] = bcast<G, j + 1>(s);
         poisoned |= !(pj > 0.0);
-        // 1 / pivot: hardware v_rcp_f64 seed + two Newton-Raphson steps -> ~1e-16
-        const double ip = rcp_nr(pj);
-        ipiv[j] = ip;
+        // 1 / pivot: hardware v_rcp_f64 seed + two Newton-Raphson steps -> ~1e-16; the second step is folded into
+        // the consumers (y1 (1 + delta) with delta = 1 - pivot y1) so that s * y1 and delta form side by side
+        const double y0 = __builtin_amdgcn_rcp(pj);
+        const double y1 = fma(fma(-pj, y0, 1.0), y0, y0);
+        const double delta = fma(-pj, y1, 1.0);
+        const double sy = s * y1;
+        ipiv[j] = fma(y1, delta, y1);
         Ur[j] = s;
-        Vr[j] = s * ip;
+        Vr[j] = fma(sy, delta, sy);
     });
 
     F1_STAMP(1);
@@ -365,14 +382,14 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         lam_io = x;
         F1_STAMP(3);
         // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2   (quadtures.py:133, V[0, :]**2)
-        double p0 = 1.0, p1 = a[0] - lam, acc = 1.0;
+        double p0 = 1.0, p1 = a[0] - lam, acc = 1.0, acc2 = 0.0;
         static_for<1, N>([&](auto Jc) {
             constexpr int j = Jc;
-            acc = fma(c[j] * p1, p1, acc);
+            if constexpr (j % 2 == 1) acc = fma(c[j] * p1, p1, acc); else acc2 = fma(c[j] * p1, p1, acc2);
             const double pn = fma(a[j] - lam, p1, -b2[j - 1] * p0);
             p0 = p1; p1 = pn;
         });
-        w = 1.0 / acc;
+        w = rcp_nr(acc + acc2);
         F1_STAMP(4);
     }
     const double qnan = __builtin_nan("");
@@ -451,7 +468,12 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
         // measurements: one coalesced 128-byte load per group every 16 steps, handed out by a lane shuffle
         constexpr int YW = (G < 16) ? G : 16;
         const int tw = (t - a.t_begin) & (YW - 1);
-        if (tw == 0) ywin = (t + (l & (YW - 1)) < a.t_end) ? yrow[t + (l & (YW - 1))] : 0.0;
+        if (tw == 0) {
+            // the loaded window is moved into its own register HERE, so that the wait for the load (vmcnt is an in-order
+            // counter: it also waits for every output store issued before) happens once per window, not at each step
+            const double ld = (t + (l & (YW - 1)) < a.t_end) ? yrow[t + (l & (YW - 1))] : 0.0;
+            asm volatile("v_mov_b64 %0, %1" : "=v"(ywin) : "v"(ld));
+        }
         const double y = __shfl(ywin, tw, YW);
         if (!dead) {
             int bad = 0;
@@ -544,11 +566,14 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                         gA = node ? dx : last;
                     }
                     double* row = TAB + l * TLD;
-                    double p = wl;
+                    {   // wl dx^n in four interleaved chains (a dependent multiply costs several issue slots)
+                        const double dx2 = dx * dx, dx4 = dx2 * dx2;
+                        double pw[4] = {wl, wl * dx, wl * dx2, wl * dx2 * dx};
 #pragma unroll
-                    for (int n = 0; n < M2; ++n) {
-                        row[n] = p;
-                        p *= dx;
+                        for (int n = 0; n < M2; ++n) {
+                            row[n] = pw[n & 3];
+                            pw[n & 3] *= dx4;
+                        }
                     }
                     nell -= log(py);
                 }
