@@ -163,30 +163,51 @@ __device__ __forceinline__ double rsq_nr(const double v) {
     return y;
 }
 
-// weighted TME moments of one node for all orders n < M2 (see the call site); KT = number of operator terms
+// weighted TME moments of one node for all orders n < M2 (see the call site); KT = number of operator terms.
+//   f_n = sum_{k <= KT} q_k C(n, k) dx^(n-k),   q_0 = 1, q_k = k! Q_k.
+// Orders n < KT are summed directly, with E_k(n) = C(n, k) dx^(n-k) advanced by Pascal's rule
+// E_k(n+1) = dx E_k(n) + E_{k-1}(n).  For n >= KT, f_n = dx^(n-KT) h_n with h_n = sum_k C(n, k) g_k, g_k = q_k dx^(KT-k),
+// and the sums h^(j)_n = sum_k C(n, k) g_{k+j} form a difference table, h^(j)_{n+1} = h^(j)_n + h^(j+1)_n (Pascal's
+// rule again, h^(j)_0 = g_j): KT additions and two multiplications per order instead of 2 KT + 1 multiply-adds.
 template <int KT, int M2>
 __device__ __forceinline__ void operator_moments(const double (&rows)[MFS_MAX_TERMS + 1], const double dx,
                                                  const double w, const double inv_sc, const bool node,
                                                  double* __restrict__ row) {
-    double Qp[KT + 1], E[KT + 1];
+    double Qp[KT + 1], E[KT + 1], h[KT + 1];
     Qp[0] = 1.0; E[0] = 1.0;
     double fact = 1.0;
 #pragma unroll
     for (int k = 1; k <= KT; ++k) { fact *= (double)k; Qp[k] = rows[k - 1] * fact; E[k] = 0.0; }
+    {   // g_k = q_k dx^(KT-k)
+        double pw = 1.0;
+#pragma unroll
+        for (int k = KT; k >= 0; --k) { h[k] = Qp[k] * pw; pw *= dx; }
+    }
     double sc_n = w;
-    for (int n = 0; n < M2; ++n) {
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0;  // independent partial sums: no single long FMA chain
+    constexpr int NLOW = (KT < M2) ? KT : M2;
+#pragma unroll
+    for (int n = 0; n < NLOW; ++n) {
+        double v0 = 0.0, v1 = 0.0;
 #pragma unroll
         for (int k = 0; k <= KT; ++k) {
-            if (k % 3 == 0) v0 = fma(Qp[k], E[k], v0);
-            else if (k % 3 == 1) v1 = fma(Qp[k], E[k], v1);
-            else v2 = fma(Qp[k], E[k], v2);
+            if (k <= n) { if (k % 2 == 0) v0 = fma(Qp[k], E[k], v0); else v1 = fma(Qp[k], E[k], v1); }
         }
-        row[n] = sc_n * ((v0 + v1) + v2);
+        row[n] = sc_n * (v0 + v1);
         sc_n *= inv_sc;
 #pragma unroll
         for (int k = KT; k >= 1; --k) E[k] = fma(dx, E[k], E[k - 1]);
         E[0] *= dx;
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) h[jj] += h[jj + 1];
+    }
+    double P = sc_n;                 // w inv_sc^KT (dx inv_sc)^(n-KT)
+    const double step = dx * inv_sc;
+#pragma unroll
+    for (int n = NLOW; n < M2; ++n) {
+        row[n] = P * h[0];
+        P *= step;
+#pragma unroll
+        for (int jj = 0; jj < KT; ++jj) h[jj] += h[jj + 1];
     }
 }
 
