@@ -253,6 +253,9 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     const int li = (l <= N) ? l : N;
     double g[N];
     static_for<0, N>([&](auto J) { g[J] = mom[li + J]; });
+    // all N reads are issued here, before the elimination starts (left alone, the scheduler sinks them next to their
+    // first uses and exposes one LDS latency per group of columns)
+    __builtin_amdgcn_sched_barrier(0);
 
     F1_STAMP(0);
     // -- Cholesky, row per lane, left-looking by column (quadtures.py:127), kept in its square-root-free form: only the
@@ -607,9 +610,13 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
                     const bool has0 = n0 < M2, has1 = n1 < M2;
                     const double* t0 = TAB + (has0 ? n0 : 0);
                     const double* t1 = TAB + (has1 ? n1 : 0);
+                    double c0[N], c1[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { c0[i] = t0[i * TLD]; c1[i] = t1[i * TLD]; }
+                    __builtin_amdgcn_sched_barrier(0);   // every read in flight before the first add (one LDS latency, not N)
                     double s0[3] = {0.0, 0.0, 0.0}, s1[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < N; ++i) { s0[i % 3] += t0[i * TLD]; s1[i % 3] += t1[i * TLD]; }
+                    for (int i = 0; i < N; ++i) { s0[i % 3] += c0[i]; s1[i % 3] += c1[i]; }
                     double acc0 = (s0[0] + s0[1]) + s0[2], acc1 = (s1[0] + s1[1]) + s1[2];
                     if (half != 0) { acc0 *= ipy; acc1 *= ipy; }
                     if (has0) { mom[n0] = acc0; bad |= !finite(acc0); }
