@@ -207,7 +207,7 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     p->fpb = ke.waves_per_block * (64 / p->G);
     p->grid = (B + p->fpb - 1) / p->fpb;
     p->lds_doubles = ke.lds_doubles_per_filter;
-    if (slot >= 3) p->lds_doubles += (model->degree + 1) * 10;  // fast path: + model table [degree + 1][kCoefRows]
+    if (slot >= 3) p->lds_doubles += ((model->degree + 4) & ~3) * 10;  // fast path: + model table [ceil4(degree + 1)][kCoefRows]
     p->lds_bytes = p->fpb * p->lds_doubles * 8;
 
     const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * model->n_rows * (model->degree + 1);

@@ -128,7 +128,7 @@ __device__ __forceinline__ bool gany(bool flag, int grp) {
 }
 
 // acc[r] = row r of the coefficient table evaluated at u, for R rows at once.  The LDS copy of the table is
-// degree-major and zero-padded to kCoefRows rows ([degree + 1][kCoefRows]): the coefficients of one degree are
+// degree-major and zero-padded to kCoefRows rows ([ceil4(degree + 1)][kCoefRows]): the coefficients of one degree are
 // contiguous, read unconditionally in wide LDS reads that are all in flight together, and the Horner recurrences of the
 // rows advance side by side -- no per-coefficient branch, no per-coefficient LDS latency.
 constexpr int kCoefRows = (MFS_MAX_TERMS + 1 + 1) & ~1;   // 9 rows (operator terms + variance), padded to 10
@@ -136,16 +136,23 @@ template <int R>
 __device__ __forceinline__ void horner_rows(const double* __restrict__ table, const int degree, const double u,
                                             double (&acc)[R]) {
     static_assert(R <= kCoefRows, "table rows");
-    const double* t = table + degree * kCoefRows;
+    // the LDS table is also zero-padded at the top to a multiple of four degrees: the coefficients of four degrees are
+    // read together (one LDS latency per four Horner steps instead of one per step; leading zeros leave acc at zero)
+    const int top = (degree + 4) & ~3;
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = t[r];
-    for (int j = degree - 1; j >= 0; --j) {
-        t -= kCoefRows;
-        double cj[R];
+    for (int r = 0; r < R; ++r) acc[r] = 0.0;
+    for (int jb = top - 4; jb >= 0; jb -= 4) {
+        const double* t = table + jb * kCoefRows;
+        double cj[4][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) cj[r] = t[r];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = fma(acc[r], u, cj[r]);
+            for (int r = 0; r < R; ++r) cj[q][r] = t[q * kCoefRows + r];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 3; q >= 0; --q)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = fma(acc[r], u, cj[q][r]);
     }
 }
 
@@ -445,9 +452,9 @@ __global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kern
 
     {   // stage the model tables and the carry
         const double* src = a.coef + (a.coef_batched ? (size_t)b * a.n_rows * J1 : 0);
-        for (int e = l; e < J1 * kCoefRows; e += G) {   // [row][degree] in HBM -> [degree][row] zero-padded in LDS
-            const int j = e / kCoefRows, r = e - j * kCoefRows;
-            S[L::oCoef + e] = (r < a.n_rows) ? src[r * J1 + j] : 0.0;
+        for (int e = l; e < ((a.degree + 4) & ~3) * kCoefRows; e += G) {   // [row][degree] in HBM -> [degree][row] in LDS,
+            const int j = e / kCoefRows, r = e - j * kCoefRows;             // zero-padded in both directions
+            S[L::oCoef + e] = (r < a.n_rows && j < J1) ? src[r * J1 + j] : 0.0;
         }
         const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
         for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + e] = (e < a.n_lik) ? ls[e] : 0.0;
