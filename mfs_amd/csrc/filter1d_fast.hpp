@@ -62,7 +62,12 @@ __device__ __forceinline__ double bcast(double v) {
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
         return __hiloint2double(hi, lo);
     } else {
-        return __shfl(v, J, G);
+        // G = 32: ds_swizzle in bit mode (and 0, or J): lane J of every 32-lane half -- the LDS crossbar like ds_bpermute,
+        // but with the lane pattern in the instruction instead of an address register computed with VALU
+        static_assert(G == 32, "lanes per filter");
+        const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), J << 5);
+        const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), J << 5);
+        return __hiloint2double(hi, lo);
     }
 }
 
