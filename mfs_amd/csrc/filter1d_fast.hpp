@@ -328,7 +328,10 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         //    monotonically and cubically to the nearest root on that side, from ANY distance.  count(x) = number of
         //    eigenvalues below x tells the lane which root that is: count == k -> step right lands on lambda_k,
         //    count == k + 1 -> step left does; otherwise bisect the count bracket [lo, hi).
-        const double rad = 2.0 * sqrt(bmax2);
+        // 2 max|b|, rounded up: only has to bound the spectrum (seed + one Newton step, then 1 + 1e-9)
+        double rb = __builtin_amdgcn_rsq(bmax2);
+        rb = fma(rb, fma(-0.5 * bmax2 * rb, rb, 0.5), rb);
+        const double rad = (bmax2 > 0.0) ? 2.000000002 * bmax2 * rb : 0.0;
         const double width = (amax - amin) + 2.0 * rad;
         double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
         const double wscale = fmax(fabs(lo), fabs(hi));
@@ -345,7 +348,11 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             const double gsel = (l < N) ? lam_io : 0.0;
             const double g1 = gsum<G>(gsel) * (1.0 / (double)N), g2 = gsum<G>(gsel * gsel) * (1.0 / (double)N);
             const double m1 = tr * (1.0 / (double)N), v_t = tr2 * (1.0 / (double)N) - m1 * m1, v_g = g2 - g1 * g1;
-            const double r = (v_t > 0.0 && v_g > 0.0) ? sqrt(v_t / v_g) : 1.0;
+            // sqrt(v_t / v_g) to ~1e-7 (it only places a start): v_t rsq(v_t v_g)
+            const double vv = v_t * v_g;
+            double rr = __builtin_amdgcn_rsq(vv);
+            rr = fma(rr, fma(-0.5 * vv * rr, rr, 0.5), rr);
+            const double r = (v_t > 0.0 && v_g > 0.0) ? v_t * rr : 1.0;
             lam_io = fma(r, lam_io - g1, m1);
         }
         if (lam_io > lo && lam_io < hi) x = lam_io;
