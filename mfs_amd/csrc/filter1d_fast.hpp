@@ -84,6 +84,20 @@ __device__ __forceinline__ void fnma_bcast(double& acc, const double u, const do
     }
 }
 
+// v_min_f64 / v_max_f64 as single instructions: fmin() / fmax() compile to a canonicalising v_max_f64 x, x in front of
+// each (signalling-NaN quieting), which doubles the cost of the Gershgorin bounds; the operands here are results of
+// arithmetic, and a NaN among them has already poisoned the rule.
+__device__ __forceinline__ double vmin_f64(const double a, const double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax_f64(const double a, const double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // sum over the G lanes of the group, result in every lane.  G = 16 is one DPP row: xor-1, xor-2 inside quads,
 // then half-row mirror and row mirror -- 2 v_mov_b32_dpp + 1 v_add_f64 per stage at VALU latency instead of
 // ds_bpermute round trips through the LDS crossbar.
@@ -312,12 +326,12 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         c[j] = piv[0] * ipiv[j];
         if constexpr (j < N - 1) {
             b2[j] = piv[j + 1] * ipiv[j];
-            bmax2 = fmax(bmax2, b2[j]);
+            bmax2 = vmax_f64(bmax2, b2[j]);
         } else {
             b2[j] = 0.0;
         }
-        amin = fmin(amin, aj);
-        amax = fmax(amax, aj);
+        amin = vmin_f64(amin, aj);
+        amax = vmax_f64(amax, aj);
     });
 
     F1_STAMP(2);
