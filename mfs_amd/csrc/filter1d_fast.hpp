@@ -53,10 +53,11 @@ __device__ __forceinline__ double bcast(double v) {
     if constexpr (G == 16) {
         return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);  // v_mov_b64_dpp row_newbcast:J
     } else if constexpr (G == 8) {
-        // two filters share a DPP row: lane J of the lower or of the upper half, picked by this lane's half
-        const double lo = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);
-        const double hi = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + 8 + J, 0xf, 0xf, false);
-        return (__lane_id() & 8) ? hi : lo;
+        // two filters share a DPP row: lane J of the lower half goes to banks 0-1, lane J of the upper half to banks 2-3
+        // (bank_mask leaves the other lanes of the destination alone, so the second move completes the first)
+        double r = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0x3, false);
+        r = __builtin_amdgcn_update_dpp(r, v, 0x150 + 8 + J, 0xf, 0xc, false);
+        return r;
     } else if constexpr (G == 64) {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), J);
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), J);
@@ -79,7 +80,7 @@ __device__ __forceinline__ void fnma_bcast(double& acc, const double u, const do
     if constexpr (G == 16) {
         asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
             : "+v"(acc) : "v"(v), "v"(u), "n"(J));
-    } else {
+    } else {   // (a bank-masked v_fmac_f64_dpp pair for G = 8 does not keep the masked lanes' accumulator: tools/diag/dpp_bank_test.hip)
         acc = fma(-u, bcast<G, J>(v), acc);
     }
 }
