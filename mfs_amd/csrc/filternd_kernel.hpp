@@ -83,7 +83,15 @@ struct NdTile {
     static constexpr int oRed = oLam + 2 * NP;       // [4 waves x 4 DPP rows][RW]
     static constexpr int oCoef = oRed + 16 * RW;     // [kNdRows][D][D]
     static constexpr int oMisc = oCoef + kNdRows * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
-    static constexpr int kDoubles = oMisc + 8;
+    // Tournament index tables, built once per launch: which rows / columns a work item touches in round r depends on
+    // (r, item) only, and recomputing it cost ~50 integer instructions per thread per round next to ~30 flops.
+    //   KT[r][P * HP + Q] = p1 | p2 << 8 | q1 << 16 | q2 << 24  (u32),   VT[r][row * HP + P] = p | q << 8  (u16)
+    static constexpr bool kTables = (2 * HP * HP <= 256) && (2 * S * HP <= 512);
+    static constexpr int oIdxK = oMisc + 8;
+    static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
+    static constexpr int oIdxV = oIdxK + nIdxK;
+    static constexpr int nIdxV = kTables ? ((NP - 1) * S * HP * 2 + 7) / 8 : 0;
+    static constexpr int kDoubles = oIdxV + nIdxV;
 };
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -386,18 +394,17 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 const int P = blk / HP, Q = blk - P * HP;
                 double* Kk = K + mB * NP * LD;
                 const double* csB = cs + mB * HP * 3;
-                int p1, p2, q1, q2;
-                tournament_pair<NP>(r, P, p1, p2);
-                tournament_pair<NP>(r, Q, q1, q2);
                 const int e0 = tid, e1 = tid + 256;
                 const bool has0 = e0 < 2 * S * HP, has1 = e1 < 2 * S * HP;
                 const int m0 = has0 ? e0 / (S * HP) : 0, f0 = has0 ? e0 - m0 * S * HP : 0, row0 = f0 / HP, P0 = f0 - row0 * HP;
                 const int m1 = has1 ? e1 / (S * HP) : 0, f1 = has1 ? e1 - m1 * S * HP : 0, row1 = f1 / HP, P1 = f1 - row1 * HP;
                 double* V0p = V + m0 * NP * LD + row0 * LD;
                 double* V1p = V + m1 * NP * LD + row1 * LD;
-                int u0, w0, u1, w1;
-                tournament_pair<NP>(r, P0, u0, w0);
-                tournament_pair<NP>(r, P1, u1, w1);
+                const unsigned kw = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[r * (HP * HP) + blk];
+                const unsigned short* vt = reinterpret_cast<const unsigned short*>(Sm + L::oIdxV) + r * (S * HP);
+                const unsigned vw0 = vt[f0], vw1 = vt[f1];
+                const int p1 = kw & 255, p2 = (kw >> 8) & 255, q1 = (kw >> 16) & 255, q2 = kw >> 24;
+                const int u0 = vw0 & 255, w0 = vw0 >> 8, u1 = vw1 & 255, w1 = vw1 >> 8;
                 // ---- loads
                 const double a11 = Kk[p1 * LD + q1], a12 = Kk[p1 * LD + q2];
                 const double a21 = Kk[p2 * LD + q1], a22 = Kk[p2 * LD + q2];
@@ -497,6 +504,24 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     const int DD = a.D * a.D;
 
     for (int e = tid; e < kNdRows * DD; e += 256) Sm[L::oCoef + e] = a.coef[e];
+    if constexpr (L::kTables) {
+        constexpr int HP = L::HP;
+        unsigned* kt = reinterpret_cast<unsigned*>(Sm + L::oIdxK);
+        unsigned short* vt = reinterpret_cast<unsigned short*>(Sm + L::oIdxV);
+        for (int e = tid; e < (NP - 1) * HP * HP; e += 256) {
+            const int r = e / (HP * HP), blk = e - r * HP * HP, Pq = blk / HP, Qq = blk - Pq * HP;
+            int p1, p2, q1, q2;
+            tournament_pair<NP>(r, Pq, p1, p2);
+            tournament_pair<NP>(r, Qq, q1, q2);
+            kt[e] = (unsigned)p1 | ((unsigned)p2 << 8) | ((unsigned)q1 << 16) | ((unsigned)q2 << 24);
+        }
+        for (int e = tid; e < (NP - 1) * S * HP; e += 256) {
+            const int r = e / (S * HP), f = e - r * S * HP, Pq = f % HP;
+            int pp, qq;
+            tournament_pair<NP>(r, Pq, pp, qq);
+            vt[e] = (unsigned short)(pp | (qq << 8));
+        }
+    }
     if (tid < 4) Sm[L::oMisc + tid] = (tid < a.n_lik) ? a.lik[tid] : 0.0;
     {
         const double* src = a.m0 + (a.m0_batched ? (size_t)b * Z : 0);
