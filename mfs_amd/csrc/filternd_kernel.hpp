@@ -85,12 +85,12 @@ struct NdTile {
     static constexpr int oMisc = oCoef + kNdRows * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
     // Tournament index tables, built once per launch: which rows / columns a work item touches in round r depends on
     // (r, item) only, and recomputing it cost ~50 integer instructions per thread per round next to ~30 flops.
-    //   KT[r][P * HP + Q] = p1 | p2 << 8 | q1 << 16 | q2 << 24  (u32),   VT[r][row * HP + P] = p | q << 8  (u16)
+    //   KT[r][P * HP + Q] = p1 | p2 << 8 | q1 << 16 | q2 << 24  (u32)
     static constexpr bool kTables = (2 * HP * HP <= 256) && (2 * S * HP <= 512);
     static constexpr int oIdxK = oMisc + 8;
     static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
     static constexpr int oIdxV = oIdxK + nIdxK;
-    static constexpr int nIdxV = kTables ? ((NP - 1) * S * HP * 2 + 7) / 8 : 0;
+    static constexpr int nIdxV = 0;
     static constexpr int kDoubles = oIdxV + nIdxV;
 };
 
@@ -389,30 +389,23 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             // One straight-line section per thread: its 2x2 block of A <- J^T A J and its two eigenvector row-pairs of
             // V <- V J.  All LDS reads are issued before any arithmetic so that one latency is exposed, not three.
             if constexpr (2 * HP * HP <= 256 && 2 * S * HP <= 512) {
+                // item (m, P, Q): the 2x2 block (pair P, pair Q) of K_m and the eigenvector entries of rows Q and Q + HP in
+                // the two columns of pair P -- both need the rotation of pair P, so an item reads two rotations, not four
                 const bool hasB = tid < 2 * HP * HP;
                 const int mB = hasB ? tid / (HP * HP) : 0, blk = hasB ? tid - mB * HP * HP : 0;
                 const int P = blk / HP, Q = blk - P * HP;
                 double* Kk = K + mB * NP * LD;
+                double* Va = V + mB * NP * LD + Q * LD;
+                double* Vb = V + mB * NP * LD + (Q + HP) * LD;
                 const double* csB = cs + mB * HP * 3;
-                const int e0 = tid, e1 = tid + 256;
-                const bool has0 = e0 < 2 * S * HP, has1 = e1 < 2 * S * HP;
-                const int m0 = has0 ? e0 / (S * HP) : 0, f0 = has0 ? e0 - m0 * S * HP : 0, row0 = f0 / HP, P0 = f0 - row0 * HP;
-                const int m1 = has1 ? e1 / (S * HP) : 0, f1 = has1 ? e1 - m1 * S * HP : 0, row1 = f1 / HP, P1 = f1 - row1 * HP;
-                double* V0p = V + m0 * NP * LD + row0 * LD;
-                double* V1p = V + m1 * NP * LD + row1 * LD;
                 const unsigned kw = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[r * (HP * HP) + blk];
-                const unsigned short* vt = reinterpret_cast<const unsigned short*>(Sm + L::oIdxV) + r * (S * HP);
-                const unsigned vw0 = vt[f0], vw1 = vt[f1];
                 const int p1 = kw & 255, p2 = (kw >> 8) & 255, q1 = (kw >> 16) & 255, q2 = kw >> 24;
-                const int u0 = vw0 & 255, w0 = vw0 >> 8, u1 = vw1 & 255, w1 = vw1 >> 8;
                 // ---- loads
                 const double a11 = Kk[p1 * LD + q1], a12 = Kk[p1 * LD + q2];
                 const double a21 = Kk[p2 * LD + q1], a22 = Kk[p2 * LD + q2];
                 const double cP = csB[3 * P], sP = csB[3 * P + 1], tP = csB[3 * P + 2];
                 const double cQ = csB[3 * Q], sQ = csB[3 * Q + 1];
-                const double c0 = cs[(m0 * HP + P0) * 3], s0 = cs[(m0 * HP + P0) * 3 + 1];
-                const double c1 = cs[(m1 * HP + P1) * 3], s1 = cs[(m1 * HP + P1) * 3 + 1];
-                const double v0p = V0p[u0], v0q = V0p[w0], v1p = V1p[u1], v1q = V1p[w1];
+                const double x0 = Va[p1], x1 = Va[p2], y0 = Vb[p1], y1 = Vb[p2];
                 // ---- arithmetic
                 double b11, b12, b21, b22;
                 if (P == Q) {
@@ -427,9 +420,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 if (hasB) {
                     Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
                     Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
+                    Va[p1] = cP * x0 - sP * x1; Va[p2] = sP * x0 + cP * x1;
+                    Vb[p1] = cP * y0 - sP * y1; Vb[p2] = sP * y0 + cP * y1;
                 }
-                if (has0) { V0p[u0] = c0 * v0p - s0 * v0q; V0p[w0] = s0 * v0p + c0 * v0q; }
-                if (has1) { V1p[u1] = c1 * v1p - s1 * v1q; V1p[w1] = s1 * v1p + c1 * v1q; }
             } else {  // larger N: the same work in strided loops
                 for (int e = tid; e < 2 * HP * HP; e += nthr) {
                     const int m = e / (HP * HP), blk = e - m * HP * HP, P = blk / HP, Q = blk - P * HP;
@@ -507,19 +500,12 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     if constexpr (L::kTables) {
         constexpr int HP = L::HP;
         unsigned* kt = reinterpret_cast<unsigned*>(Sm + L::oIdxK);
-        unsigned short* vt = reinterpret_cast<unsigned short*>(Sm + L::oIdxV);
         for (int e = tid; e < (NP - 1) * HP * HP; e += 256) {
             const int r = e / (HP * HP), blk = e - r * HP * HP, Pq = blk / HP, Qq = blk - Pq * HP;
             int p1, p2, q1, q2;
             tournament_pair<NP>(r, Pq, p1, p2);
             tournament_pair<NP>(r, Qq, q1, q2);
             kt[e] = (unsigned)p1 | ((unsigned)p2 << 8) | ((unsigned)q1 << 16) | ((unsigned)q2 << 24);
-        }
-        for (int e = tid; e < (NP - 1) * S * HP; e += 256) {
-            const int r = e / (S * HP), f = e - r * S * HP, Pq = f % HP;
-            int pp, qq;
-            tournament_pair<NP>(r, Pq, pp, qq);
-            vt[e] = (unsigned short)(pp | (qq << 8));
         }
     }
     if (tid < 4) Sm[L::oMisc + tid] = (tid < a.n_lik) ? a.lik[tid] : 0.0;
