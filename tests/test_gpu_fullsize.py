@@ -136,3 +136,30 @@ def test_config4_nll_grid_per_replicate_theta():
     for k in range(keys):
         i, j = np.unravel_index(np.argmin(surf[k]), surf[k].shape)
         assert 1.0 < g1[i, j] < 6.0 and 1.5 < g2[i, j] < 5.0
+
+
+def test_config5_length_nd_modes_agree():
+    """BASELINE config 5 at full length (d = 2, N = 6, T = 500) on a slice of the batch: no oracle can follow 500 steps
+    of it in test time, so the size-independent property is the reference's own one (tests/test_filtering.py:168-242):
+    the central and the scaled-central filters carry the same means and NLL."""
+    from mfs_amd.multi_dims import filtering as fnd, moments as mnd, ss_models as snd
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+        gram_and_hankel_indices_graded_lexico
+    N, T, B = 6, 500, 48
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, pmf, _ = snd.prey_predator(mi)
+    fns = mnd.sde_cond_moments_tme(drift, disp, dt, 2)
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=77)
+    cmss, means_c, nell_c, fn = fnd.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms,
+                                                         gs.mean, return_first_nan=True)
+    scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))
+    scmss, means_s, scales, nell_s = fnd.moment_filter_nd_scms((fns[2], 'multi-index'), fns[4], pmf, ys, (mi, inds),
+                                                               gs.cms / np.prod(scale0 ** mi, axis=-1), gs.mean, scale0)
+    alive = fn < 0
+    assert alive.mean() > 0.9
+    both = alive & np.isfinite(nell_s)
+    assert both.mean() > 0.9
+    npt.assert_allclose(nell_s[both], nell_c[both], rtol=1e-5)
+    npt.assert_allclose(means_s[both], means_c[both], rtol=1e-5)
+    npt.assert_allclose(scales[both] ** 2, np.stack([cmss[both][:, :, 5], cmss[both][:, :, 3]], axis=-1), rtol=1e-3)
