@@ -360,6 +360,11 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
 #endif
 
         for (int r = 0; r < NP - 1; ++r) {
+            // this round's index word is fetched and unpacked before the rotations / the barrier, off the update's path
+            unsigned kw = 0;
+            if constexpr (L::kTables) kw = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[r * (HP * HP) + ((tid < 2 * HP * HP) ? tid % (HP * HP) : 0)];
+            const int p1 = kw & 255, p2 = (kw >> 8) & 255, q1 = (kw >> 16) & 255, q2 = kw >> 24;
+            const int o11 = p1 * LD + q1, o12 = p1 * LD + q2, o21 = p2 * LD + q1, o22 = p2 * LD + q2;
             if (tid < 2 * HP) {
                 const int m = tid / HP, P = tid - m * HP;
                 double* Kk = K + m * NP * LD;
@@ -398,11 +403,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 double* Va = V + mB * NP * LD + Q * LD;
                 double* Vb = V + mB * NP * LD + (Q + HP) * LD;
                 const double* csB = cs + mB * HP * 3;
-                const unsigned kw = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[r * (HP * HP) + blk];
-                const int p1 = kw & 255, p2 = (kw >> 8) & 255, q1 = (kw >> 16) & 255, q2 = kw >> 24;
                 // ---- loads
-                const double a11 = Kk[p1 * LD + q1], a12 = Kk[p1 * LD + q2];
-                const double a21 = Kk[p2 * LD + q1], a22 = Kk[p2 * LD + q2];
+                const double a11 = Kk[o11], a12 = Kk[o12];
+                const double a21 = Kk[o21], a22 = Kk[o22];
                 const double cP = csB[3 * P], sP = csB[3 * P + 1], tP = csB[3 * P + 2];
                 const double cQ = csB[3 * Q], sQ = csB[3 * Q + 1];
                 const double x0 = Va[p1], x1 = Va[p2], y0 = Vb[p1], y1 = Vb[p2];
@@ -418,8 +421,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 }
                 // ---- stores (every item touches only its own elements)
                 if (hasB) {
-                    Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
-                    Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
+                    Kk[o11] = b11; Kk[o12] = b12;
+                    Kk[o21] = b21; Kk[o22] = b22;
                     Va[p1] = cP * x0 - sP * x1; Va[p2] = sP * x0 + cP * x1;
                     Vb[p1] = cP * y0 - sP * y1; Vb[p2] = sP * y0 + cP * y1;
                 }
