@@ -365,6 +365,18 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             if constexpr (L::kTables) kw = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[r * (HP * HP) + ((tid < 2 * HP * HP) ? tid % (HP * HP) : 0)];
             const int p1 = kw & 255, p2 = (kw >> 8) & 255, q1 = (kw >> 16) & 255, q2 = kw >> 24;
             const int o11 = p1 * LD + q1, o12 = p1 * LD + q2, o21 = p2 * LD + q1, o22 = p2 * LD + q2;
+            // ... and so are the block and the eigenvector entries the item will rotate: the rotations (below) only read
+            // K and write their own records, so these loads are in flight while wave 0 works through the rotation chain
+            double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0, x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
+            if constexpr (L::kTables) {
+                const int mB = (tid < 2 * HP * HP) ? tid / (HP * HP) : 0;
+                const int Q = ((tid < 2 * HP * HP) ? tid % (HP * HP) : 0) % HP;
+                const double* Kk = K + mB * NP * LD;
+                const double* Va = V + mB * NP * LD + Q * LD;
+                const double* Vb = V + mB * NP * LD + (Q + HP) * LD;
+                a11 = Kk[o11]; a12 = Kk[o12]; a21 = Kk[o21]; a22 = Kk[o22];
+                x0 = Va[p1]; x1 = Va[p2]; y0 = Vb[p1]; y1 = Vb[p2];
+            }
             if (tid < 2 * HP) {
                 const int m = tid / HP, P = tid - m * HP;
                 double* Kk = K + m * NP * LD;
@@ -403,12 +415,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 double* Va = V + mB * NP * LD + Q * LD;
                 double* Vb = V + mB * NP * LD + (Q + HP) * LD;
                 const double* csB = cs + mB * HP * 3;
-                // ---- loads
-                const double a11 = Kk[o11], a12 = Kk[o12];
-                const double a21 = Kk[o21], a22 = Kk[o22];
+                // ---- the two rotations
                 const double cP = csB[3 * P], sP = csB[3 * P + 1], tP = csB[3 * P + 2];
                 const double cQ = csB[3 * Q], sQ = csB[3 * Q + 1];
-                const double x0 = Va[p1], x1 = Va[p2], y0 = Vb[p1], y1 = Vb[p2];
                 // ---- arithmetic
                 double b11, b12, b21, b22;
                 if (P == Q) {
