@@ -459,8 +459,10 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 // ---------------------------------------------------------------------------------------------------------------
 // the filter kernel (fast path)
 // ---------------------------------------------------------------------------------------------------------------
+// two waves per SIMD is the register budget that holds the unrolled state without scratch at every N (asking for three
+// at N <= 8 spilled 24 dwords per lane and measured 12 % slower on config 4; four was 30 % slower)
 template <int N, int G, int WPB>
-__global__ __launch_bounds__(WPB * 64, (N <= 8) ? 3 : 2) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
+__global__ __launch_bounds__(WPB * 64, 2) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
     using L = FastTile<N, G>;
     constexpr int M2 = L::M2, TLD = L::TLD;
     constexpr int FPW = 64 / G;
