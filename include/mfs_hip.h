@@ -177,6 +177,14 @@ int mfs_characteristic_1d(int N, int count, const double* ms, const double* mean
                           const double* zs, double* out, int device, void* stream);
 
 /*
+ * ---- diagnostic: the kernels' own elementary functions -------------------------------------------------------------
+ * The 1-D kernel evaluates exp / tanh / log with short in-line routines instead of the ocml ones (the reference uses
+ * jnp.exp / jnp.tanh / jnp.log inside its model callables, mfs/one_dim/ss_models.py:37-47).  This entry point applies
+ * them to an array so that the tests can bound their error against libm.  which: 0 exp, 1 tanh, 2 log.  Host pointers.
+ */
+int mfs_elementary(int which, int n, const double* x, double* out, int device);
+
+/*
  * ---- N-D moment filter (d = 2), host pointers ------------------------------------------------------------------
  * Replaces moment_filter_nd_rms / moment_filter_nd_cms / moment_filter_nd_scms (mfs/multi_dims/filtering.py:283-344,
  * 210-280, 33-207) for B replicates, with either transition family the reference offers.

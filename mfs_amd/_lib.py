@@ -83,6 +83,7 @@ _SIGNATURES = [
     ('mfs_plan_nd_run', _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ('mfs_plan_nd_destroy', _i, [_vp]),
     ('mfs_plan_nd_geometry', _i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ('mfs_elementary', _i, [_i, _i, _vp, _vp, _i]),
     ('mfs_comm_unique_id', _i, [_vp]),
     ('mfs_comm_init', _i, [_vpp, _vp, _i, _i, _i]),
     ('mfs_allgather_nell', _i, [_vp, _vp, _vp, _u64, _vp]),

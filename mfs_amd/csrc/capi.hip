@@ -21,6 +21,7 @@ Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
 struct NdEntry { FilterNdLaunch launch, launch_gauss; int S, Z, lds_bytes; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
+hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s);
 }
 
 namespace {
@@ -658,6 +659,26 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     hipFree(d_scale0); hipFree(d_scales);
     if (rc != MFS_OK) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// diagnostic: the kernels' elementary functions
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int mfs_elementary(int which, int n, const double* x, double* out, int device) {
+    if (which < 0 || which > 2) return fail(MFS_EINVAL, "which = %d outside {0 exp, 1 tanh, 2 log}", which);
+    if (n < 0) return fail(MFS_EINVAL, "negative n");
+    if (n == 0) return MFS_OK;
+    if (!x || !out) return fail(MFS_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(device));
+    double *d_x = nullptr, *d_o = nullptr;
+    hipError_t e = hipMalloc((void**)&d_x, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_o, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_x, x, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = mfs::launch_elementary(which, n, d_x, d_o, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost);
+    hipFree(d_x); hipFree(d_o);
+    if (e != hipSuccess) return fail(MFS_EHIP, "mfs_elementary: %s", hipGetErrorString(e));
     return MFS_OK;
 }
 

@@ -183,11 +183,67 @@ __device__ __forceinline__ double rcp_nr(const double v) {
     return y;
 }
 
+// the same, but 1 / (+-inf) = 0 like a true divide (the Newton steps alone turn it into NaN)
+__device__ __forceinline__ double rcp_sat(const double v) {
+    const double y0 = __builtin_amdgcn_rcp(v);
+    double y = fma(fma(-v, y0, 1.0), y0, y0);
+    y = fma(fma(-v, y, 1.0), y, y);
+    return (y0 == 0.0) ? y0 : y;
+}
+
 __device__ __forceinline__ double rsq_nr(const double v) {
     double y = __builtin_amdgcn_rsq(v);
     y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
     y = fma(y, fma(-0.5 * v * y, y, 0.5), y);
     return y;
+}
+
+// ---- elementary functions of the step, written for instruction count (the kernel is VALU-issue bound on one wave per
+// SIMD): ~22 / 33 / 34 VALU instructions for exp / tanh / log against 34 / 155 / 90 for the ocml routines.  Absolute
+// accuracy ~1-2 ulp of the result's magnitude scale; tanh keeps ABSOLUTE (not relative) accuracy near zero, which is
+// what a polynomial in tanh x needs.
+__device__ __forceinline__ double fast_exp(const double y) {
+    // e^y = 2^k e^r, k = rint(y / ln 2), |r| <= ln 2 / 2, Taylor to degree 13 (r^14 / 14! < 5e-18)
+    const double yc = vmin_f64(vmax_f64(y, -745.5), 710.0);     // e^710 = +inf as in libm (the clamp would swallow a NaN: restored below)
+    const double k = __builtin_rint(yc * 1.4426950408889634);
+    double r = fma(k, -0.6931471803691238, yc);                  // ln 2 split: hi part has 21 trailing zero bits
+    r = fma(k, -1.9082149292705877e-10, r);
+    double p = 1.6059043836821613e-10;                           // 1 / 13!
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double e = ldexp(p, (int)k);
+    return (y != y) ? y : e;
+}
+
+__device__ __forceinline__ double fast_tanh(const double x) {
+    const double a2 = vmin_f64(fabs(x) + fabs(x), 40.0);        // tanh(20) rounds to 1
+    const double e = fast_exp(a2);
+    const double t = fma(-2.0, rcp_nr(e + 1.0), 1.0);            // 1 - 2 / (e^{2|x|} + 1)
+    return (x != x) ? x : copysign(t, x);
+}
+
+// natural logarithm of a positive finite number (anything else gives a non-finite result, which is all the caller needs:
+// a non-finite negative log-likelihood poisons the replicate)
+__device__ __forceinline__ double fast_log(const double v) {
+    // v = m 2^e, m in [0.5, 1): ln m from the fp32 hardware log as a seed y0 and one exact correction
+    // ln m = y0 + log1p(m e^{-y0} - 1), |m e^{-y0} - 1| ~ 1e-7
+    const double m = __builtin_amdgcn_frexp_mant(v);
+    const int ex = __builtin_amdgcn_frexp_exp(v);
+    const double y0 = (double)(__builtin_amdgcn_logf((float)m) * 0.6931471805599453f);
+    const double d = fma(m, fast_exp(-y0), -1.0);
+    const double lnm = y0 + fma(-0.5 * d, d, d);
+    return fma((double)ex, 0.6931471805599453, lnm);
 }
 
 // weighted TME moments of one node for all orders n < M2 (see the call site); KT = number of operator terms.
@@ -264,6 +320,11 @@ __device__ __forceinline__ double likelihood_fast(const int kind, const double* 
         const double rate = log(1.0 + exp(lp[0] * x));
         const double lf = (y >= 0.0 && y <= (double)kLfacMax && y == floor(y)) ? lfac[(int)y] : log_factorial(y);
         return exp(y * log(rate) - rate - lf);
+    }
+    if (kind == MFS_LIK_BERNOULLI_LOGISTIC) {
+        const double z = lp[0] + x * (lp[1] + x * (lp[2] + x * lp[3]));
+        const double p = rcp_sat(1.0 + fast_exp(-z));   // e^{-z} may be +inf: p = 0, as 1 / (1 + inf) upstream
+        return (y > 0.5) ? p : 1.0 - p;
     }
     return likelihood(kind, lp, y, x);
 }
@@ -447,7 +508,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             const double pn = fma(a[j] - lam, p1, -b2[j - 1] * p0);
             p0 = p1; p1 = pn;
         });
-        w = rcp_nr(acc + acc2);
+        w = rcp_sat(acc + acc2);   // the sum overflows for the outermost nodes of large rules: weight 0, not NaN
         F1_STAMP(4);
     }
     const double qnan = __builtin_nan("");
@@ -551,8 +612,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_fast_kernel(const Filter
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[11 + half] += g_1d_stamps[10] - it_before;
 #endif
                 F1_STAMP_BEGIN;
-                const double u = (a.umap == MFS_U_TANH) ? tanh(x) : x;
-                double c = 0.0, inv_sc = 1.0, py = 1.0;
+                const double u = (a.umap == MFS_U_TANH) ? fast_tanh(x) : x;
+                double c = 0.0, inv_sc = 1.0, py = 1.0, ipy = 1.0;
                 if (half == 0) {
                     // ---- prediction (filtering.py:76-79 / 144-148 / 221-225)
                     // every row of the model table at this lane's node, in one pass over the degrees
@@ -612,12 +673,13 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_fast_kernel(const Filter
                     // ---- update (filtering.py:82-85 / 151-157 / 228-236)
                     const double wl = node ? w * likelihood_fast(a.lik_kind, lp, S + L::oLfac, y, x) : 0.0;
                     py = gsum<G>(wl);
+                    ipy = rcp_nr(py);
                     if (a.mode != MFS_MODE_RAW) {
-                        mean = gsum<G>(wl * x) / py;
+                        mean = gsum<G>(wl * x) * ipy;
                         c = mean;
                     }
                     if (a.mode == MFS_MODE_SCALED) {
-                        scale = sqrt(gsum<G>(wl * (x - c) * (x - c)) / py);
+                        scale = sqrt(gsum<G>(wl * (x - c) * (x - c)) * ipy);
                         inv_sc = 1.0 / scale;
                     }
                     const double dx = (x - c) * inv_sc;
@@ -635,11 +697,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_fast_kernel(const Filter
                             pw[n & 3] *= dx4;
                         }
                     }
-                    nell -= log(py);
+                    nell -= fast_log(py);
                 }
                 F1_STAMP(5 + half);
                 wave_sync();
-                const double ipy = 1.0 / py;
                 {   // column sums of the contribution table: each lane owns moments l and l + G (2N <= 2G - 2), summed
                     // together in three partial sums each -- a dependent add costs several issue slots on one wave
                     const int n0 = l, n1 = l + G;

@@ -28,6 +28,18 @@ void reg_nd() {
     if constexpr (N < 7) reg_nd<N + 1>();
 }
 
+// diagnostic: the kernels' own elementary functions on an array (tests bound their error against libm)
+__global__ void elementary_kernel(const int which, const int n, const double* __restrict__ x, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    out[i] = (which == 0) ? fast_exp(v) : (which == 1) ? fast_tanh(v) : fast_log(v);
+}
+hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s) {
+    hipLaunchKernelGGL(elementary_kernel, dim3((n + 255) / 256), dim3(256), 0, s, which, n, d_x, d_out);
+    return hipGetLastError();
+}
+
 struct NdRegistrar { NdRegistrar() { reg_nd<2>(); } };
 static NdRegistrar nd_registrar_instance;
 

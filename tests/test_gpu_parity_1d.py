@@ -324,3 +324,34 @@ def test_lane_group_boundaries_and_maximum_order(N):
         kf_m, kf_v, kf_nell = mdl['kf'](ys[b])
         assert np.abs(means[b] - kf_m).max() < (2e-3 if N <= 8 else 1e-6)
         npt.assert_allclose(nell[b], kf_nell, rtol=1e-4 if N <= 8 else 1e-8)
+
+
+def test_kernel_elementary_functions_against_libm():
+    """The fast kernel's in-line exp / tanh / log (mfs_elementary): a few ulp of the result, tanh in ABSOLUTE terms near
+    zero (it feeds polynomials in tanh x), non-finite in -> non-finite out."""
+    import ctypes as C
+    from mfs_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+
+    def run(which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty_like(x)
+        _lib.check(L.mfs_elementary(which, x.size, _lib.ptr(x), _lib.ptr(out), 0))
+        return out
+
+    x = np.concatenate([rng.uniform(-700, 700, 20000), rng.uniform(-2, 2, 20000), [0.0, -0.0, 1e-300, -745.0, 709.7]])
+    got, ref = run(0, x), np.exp(x)
+    assert np.max(np.abs(got - ref) / ref) < 4e-16
+    assert np.all(run(0, np.array([709.9, 800.0, np.inf])) == np.inf) and np.all(run(0, np.array([-800.0, -np.inf])) == 0.0)
+    x = np.concatenate([rng.uniform(-25, 25, 20000), rng.uniform(-1e-3, 1e-3, 20000), [0.0, 30.0, -30.0, 1e-200]])
+    got, ref = run(1, x), np.tanh(x)
+    assert np.max(np.abs(got - ref)) < 3e-16
+    big = np.abs(x) > 1e-12
+    assert np.all(np.sign(got[big]) == np.sign(x[big]))
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 20000), rng.uniform(0.5, 2.0, 20000), [1.0, 5e-324, 1.7e308]])
+    got, ref = run(2, x), np.log(x)
+    assert np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)) < 4e-16
+    bad = run(2, np.array([0.0, -1.0, np.nan, np.inf]))
+    assert not np.any(np.isfinite(bad))
+    assert np.all(np.isnan(run(0, np.array([np.nan])))) and np.all(np.isnan(run(1, np.array([np.nan]))))
