@@ -243,7 +243,9 @@ __device__ __forceinline__ double fast_log(const double v) {
     const double y0 = (double)(__builtin_amdgcn_logf((float)m) * 0.6931471805599453f);
     const double d = fma(m, fast_exp(-y0), -1.0);
     const double lnm = y0 + fma(-0.5 * d, d, d);
-    return fma((double)ex, 0.6931471805599453, lnm);
+    const double r = fma((double)ex, 0.6931471805599453, lnm);
+    const double inf = __builtin_inf();
+    return (v == 0.0) ? -inf : (v == inf) ? inf : r;      // log 0 = -inf, log inf = inf as in libm
 }
 
 // weighted TME moments of one node for all orders n < M2 (see the call site); KT = number of operator terms.
@@ -317,9 +319,9 @@ constexpr double kLagStop = MFS_LAG_STOP;
 __device__ __forceinline__ double likelihood_fast(const int kind, const double* __restrict__ lp,
                                                   const double* __restrict__ lfac, const double y, const double x) {
     if (kind == MFS_LIK_POISSON_SOFTPLUS) {
-        const double rate = log(1.0 + exp(lp[0] * x));
+        const double rate = fast_log(1.0 + fast_exp(lp[0] * x));
         const double lf = (y >= 0.0 && y <= (double)kLfacMax && y == floor(y)) ? lfac[(int)y] : log_factorial(y);
-        return exp(y * log(rate) - rate - lf);
+        return fast_exp(y * fast_log(rate) - rate - lf);
     }
     if (kind == MFS_LIK_BERNOULLI_LOGISTIC) {
         const double z = lp[0] + x * (lp[1] + x * (lp[2] + x * lp[3]));
