@@ -328,6 +328,10 @@ __device__ __forceinline__ double likelihood_fast(const int kind, const double* 
         const double p = rcp_sat(1.0 + fast_exp(-z));   // e^{-z} may be +inf: p = 0, as 1 / (1 + inf) upstream
         return (y > 0.5) ? p : 1.0 - p;
     }
+    if (kind == MFS_LIK_GAUSSIAN) {
+        const double r = y - fma(lp[0], x, lp[1]);
+        return fast_exp(-0.5 * r * r * rcp_nr(lp[2])) * rsq_nr(6.283185307179586476925 * lp[2]);
+    }
     return likelihood(kind, lp, y, x);
 }
 

@@ -151,6 +151,18 @@ __device__ __forceinline__ double poly2d(const double* __restrict__ c, const int
     return acc;
 }
 
+// the Bernoulli-logistic likelihood (mfs/multi_dims/ss_models.py:63-67) with the in-line exponential; other kinds through
+// the generic routine
+__device__ __forceinline__ double likelihood_nd(const int kind, const double* __restrict__ lp, const double y,
+                                                const double x) {
+    if (kind == MFS_LIK_BERNOULLI_LOGISTIC) {
+        const double z = lp[0] + x * (lp[1] + x * (lp[2] + x * lp[3]));
+        const double p = rcp_sat(1.0 + fast_exp(-z));
+        return (y > 0.5) ? p : 1.0 - p;
+    }
+    return likelihood(kind, lp, y, x);
+}
+
 // pair p of round r in the round-robin tournament on NP players
 template <int NP>
 __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p, int& q) {
@@ -574,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                             s3 = fma(w, poly2d(coef + v1 * DD, a.D, a.ext[v1], x0, x1), s3);
                         }
                     } else {
-                        const double wl = w * likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
+                        const double wl = w * likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
                         s0 = fma(wl, x0, s0); s1 = fma(wl, x1, s1); s4 += wl;
                     }
                 }
@@ -599,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 } else {
                     py = s4;
                     if (a.mode != MFS_MODE_RAW) { c0 = s0 / py; c1 = s1 / py; }
-                    nell -= log(py);
+                    nell -= fast_log(py);
                 }
                 ND_STAMP(6);
                 // ---- pass 2: every moment about the new centre.  One node per thread per sweep of the node list; the
@@ -729,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                             pxA0[0] = pxA1[0] = 1.0;
 #pragma unroll
                             for (int p = 1; p < P; ++p) { pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1); }
-                            wA *= likelihood(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
+                            wA *= likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
                         }
                         static_for<0, 2 * N>([&](auto Sc) {
                             constexpr int sd = Sc;
