@@ -384,14 +384,13 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 
     F1_STAMP(1);
     // -- Jacobi matrix: a_j = K_jj, b2_j = K_{j+1,j}^2, and the weight normalisers c_j = piv_0 / piv_j
-    double a[N], b2[N], c[N];
+    double a[N], b2[N];
     double amin = 1.79e308, amax = -1.79e308, bmax2 = 0.0;
     static_for<0, N>([&](auto Jc) {
         constexpr int j = Jc;
         double aj = sub[j] * ipiv[j];
         if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
         a[j] = aj;
-        c[j] = piv[0] * ipiv[j];
         if constexpr (j < N - 1) {
             b2[j] = piv[j + 1] * ipiv[j];
             bmax2 = vmax_f64(bmax2, b2[j]);
@@ -506,15 +505,15 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         lam = x;
         lam_io = x;
         F1_STAMP(3);
-        // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2   (quadtures.py:133, V[0, :]**2)
-        double p0 = 1.0, p1 = a[0] - lam, acc = 1.0, acc2 = 0.0;
+        // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2, c_j = piv_0 / piv_j  (quadtures.py:133, V[0, :]**2)
+        double p0 = 1.0, p1 = a[0] - lam, acc = ipiv[0], acc2 = 0.0;
         static_for<1, N>([&](auto Jc) {
             constexpr int j = Jc;
-            if constexpr (j % 2 == 1) acc = fma(c[j] * p1, p1, acc); else acc2 = fma(c[j] * p1, p1, acc2);
+            if constexpr (j % 2 == 1) acc = fma(ipiv[j] * p1, p1, acc); else acc2 = fma(ipiv[j] * p1, p1, acc2);
             const double pn = fma(a[j] - lam, p1, -b2[j - 1] * p0);
             p0 = p1; p1 = pn;
         });
-        w = rcp_sat(acc + acc2);   // the sum overflows for the outermost nodes of large rules: weight 0, not NaN
+        w = rcp_sat(piv[0] * (acc + acc2));   // the sum overflows for the outermost nodes of large rules: weight 0, not NaN
         F1_STAMP(4);
     }
     const double qnan = __builtin_nan("");
