@@ -356,6 +356,11 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     //    pivots d_j = L_jj^2 and the sub-diagonal enter the Jacobi matrix below, and L_ik L_jk = u_ik u_jk / d_k with the
     //    unnormalised columns u, so no square root is ever taken.  u_jk / d_k reaches the other lanes by DPP.
     double Ur[N], Vr[N];             // u_lk and u_lk / d_k of this lane's row
+    // G = 32: a group spans two DPP rows, and row_newbcast only reaches inside a row.  gfx950's v_permlane16_swap on
+    // (v, copy of v) leaves the even row's data in both rows of one register and the odd row's in both rows of the
+    // other: with those two copies of every u_lk / d_k the broadcast is again the DPP operand of the multiply-add
+    // (lane j < 16 from the first copy, else from the second), instead of two ds_swizzle round trips per term.
+    double VrA[(G == 32) ? ((N < 16) ? N : 16) : 1], VrB[(G == 32) ? N : 1];
     double piv[N], sub[N], ipiv[N];  // group-uniform
     bool poisoned = false;
     static_for<0, N>([&](auto Jc) {
@@ -363,7 +368,13 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         double s = g[j], s2 = 0.0;   // two partial sums: the dot product is not one dependent chain
         static_for<0, j>([&](auto Kc) {
             constexpr int k = Kc;
-            if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<G, j>(s, Ur[k], Vr[k]);   // k = j - 1 (the late one) lands here
+            if constexpr (G == 32) {
+                if constexpr (j < 16) {
+                    if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<16, j>(s, Ur[k], VrA[k]); else fnma_bcast<16, j>(s2, Ur[k], VrA[k]);
+                } else {
+                    if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<16, j - 16>(s, Ur[k], VrB[k]); else fnma_bcast<16, j - 16>(s2, Ur[k], VrB[k]);
+                }
+            } else if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<G, j>(s, Ur[k], Vr[k]);   // k = j - 1 (the late one) lands here
             else fnma_bcast<G, j>(s2, Ur[k], Vr[k]);
         });
         if constexpr (j >= 2) s += s2;
@@ -380,6 +391,13 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         ipiv[j] = fma(y1, delta, y1);
         Ur[j] = s;
         Vr[j] = fma(sy, delta, sy);
+        if constexpr (G == 32) {
+            const int lo = __double2loint(Vr[j]), hi = __double2hiint(Vr[j]);
+            const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+            const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+            if constexpr (j < 16) VrA[j] = __hiloint2double(rh[0], rl[0]);
+            VrB[j] = __hiloint2double(rh[1], rl[1]);
+        }
     });
 
     F1_STAMP(1);
@@ -525,10 +543,11 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 // ---------------------------------------------------------------------------------------------------------------
 // the filter kernel (fast path)
 // ---------------------------------------------------------------------------------------------------------------
-// two waves per SIMD is the register budget that holds the unrolled state without scratch at every N (asking for three
-// at N <= 8 spilled 24 dwords per lane and measured 12 % slower on config 4; four was 30 % slower)
+// two waves per SIMD is the register budget that holds the unrolled state without scratch up to N = 16 (asking for
+// three at N <= 8 spilled 24 dwords per lane and measured 12 % slower on config 4; four was 30 % slower); the 32- and
+// 64-lane instantiations (N > 16) take the whole register file of a SIMD lane: their state does not fit in 256 VGPRs
 template <int N, int G, int WPB>
-__global__ __launch_bounds__(WPB * 64, 2) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
+__global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
     using L = FastTile<N, G>;
     constexpr int M2 = L::M2, TLD = L::TLD;
     constexpr int FPW = 64 / G;
