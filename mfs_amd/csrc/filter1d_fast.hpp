@@ -109,9 +109,34 @@ __device__ __forceinline__ double dpp_move(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// gfx950 lane swaps: v_permlane16_swap on (v, copy of v) leaves the even DPP row's data in both rows of a pair in one
+// result and the odd row's in the other; v_permlane32_swap does the same with the two 32-lane halves of the wave
+__device__ __forceinline__ void row_dup(const double v, double& even_rows, double& odd_rows) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    even_rows = __hiloint2double(rh[0], rl[0]);
+    odd_rows = __hiloint2double(rh[1], rl[1]);
+}
+__device__ __forceinline__ void half_dup(const double v, double& lower, double& upper) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    lower = __hiloint2double(rh[0], rl[0]);
+    upper = __hiloint2double(rh[1], rl[1]);
+}
+
 template <int G>
 __device__ __forceinline__ double gsum(double v) {
-    if constexpr (G == 16) {
+    if constexpr (G == 32 || G == 64) {
+        // row sums by DPP, then the rows of a pair (and, for a whole-wave group, the two halves) through lane swaps:
+        // every lane adds the same numbers in the same order
+        double a, b;
+        row_dup(gsum<16>(v), a, b);
+        double t = a + b;
+        if constexpr (G == 64) { half_dup(t, a, b); t = a + b; }
+        return t;
+    } else if constexpr (G == 16) {
         v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
         v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
         v += dpp_move<0x141>(v);  // row_half_mirror
@@ -392,11 +417,10 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         Ur[j] = s;
         Vr[j] = fma(sy, delta, sy);
         if constexpr (G == 32) {
-            const int lo = __double2loint(Vr[j]), hi = __double2hiint(Vr[j]);
-            const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-            const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-            if constexpr (j < 16) VrA[j] = __hiloint2double(rh[0], rl[0]);
-            VrB[j] = __hiloint2double(rh[1], rl[1]);
+            double va, vb;
+            row_dup(Vr[j], va, vb);
+            if constexpr (j < 16) VrA[j] = va;
+            VrB[j] = vb;
         }
     });
 
