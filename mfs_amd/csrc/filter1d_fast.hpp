@@ -644,6 +644,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
             asm volatile("v_mov_b64 %0, %1" : "=v"(ywin) : "v"(ld));
         }
         const double y = __shfl(ywin, tw, YW);
+        double out0 = qnan, out1 = qnan;   // this lane's two moments of the step, kept in registers for the output store
         if (!dead) {
             int bad = 0;
             double gB = qnan;
@@ -766,6 +767,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
                     if (half != 0) { acc0 *= ipy; acc1 *= ipy; }
                     if (has0) { mom[n0] = acc0; bad |= !finite(acc0); }
                     if (has1) { mom[n1] = acc1; bad |= !finite(acc1); }
+                    out0 = acc0; out1 = acc1;
                 }
                 wave_sync();
                 F1_STAMP(7);
@@ -782,7 +784,8 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
         }
         if (a.out_mom) {
             double* dst = a.out_mom + ((size_t)b * a.T + t) * M2;
-            for (int n = l; n < M2; n += G) dst[n] = mom[n];
+            if (l < M2) dst[l] = out0;
+            if (l + G < M2) dst[l + G] = out1;
         }
         if (l == 0) {
             if (a.out_mean) a.out_mean[(size_t)b * a.T + t] = mean;
