@@ -275,49 +275,27 @@ __device__ __forceinline__ double fast_log(const double v) {
 
 // weighted TME moments of one node for all orders n < M2 (see the call site); KT = number of operator terms.
 //   f_n = sum_{k <= KT} q_k C(n, k) dx^(n-k),   q_0 = 1, q_k = k! Q_k.
-// Orders n < KT are summed directly, with E_k(n) = C(n, k) dx^(n-k) advanced by Pascal's rule
-// E_k(n+1) = dx E_k(n) + E_{k-1}(n).  For n >= KT, f_n = dx^(n-KT) h_n with h_n = sum_k C(n, k) g_k, g_k = q_k dx^(KT-k),
-// and the sums h^(j)_n = sum_k C(n, k) g_{k+j} form a difference table, h^(j)_{n+1} = h^(j)_n + h^(j+1)_n (Pascal's
-// rule again, h^(j)_0 = g_j): KT additions and two multiplications per order instead of 2 KT + 1 multiply-adds.
+// With G^(j)_n = sum_k C(n, k) q_{k+j} dx^(n-k) (so f_n = G^(0)_n, G^(j)_0 = q_j, G^(KT)_n = q_KT dx^n), Pascal's rule gives
+// G^(j)_{n+1} = dx G^(j)_n + G^(j+1)_n: KT multiply-adds and one multiplication per order, the weight folded into the
+// start values and, in scaled mode, the scale folded into dx and q_k (f_n / s^n = the same sums with dx / s, q_k / s^k).
 template <int KT, int M2>
 __device__ __forceinline__ void operator_moments(const double (&rows)[MFS_MAX_TERMS + 1], const double dx,
                                                  const double w, const double inv_sc, const bool node,
                                                  double* __restrict__ row) {
-    double Qp[KT + 1], E[KT + 1], h[KT + 1];
-    Qp[0] = 1.0; E[0] = 1.0;
-    double fact = 1.0;
+    double Gt[KT + 1];
+    Gt[0] = w;
+    {
+        double fs = w;   // w k! / s^k
 #pragma unroll
-    for (int k = 1; k <= KT; ++k) { fact *= (double)k; Qp[k] = rows[k - 1] * fact; E[k] = 0.0; }
-    {   // g_k = q_k dx^(KT-k)
-        double pw = 1.0;
-#pragma unroll
-        for (int k = KT; k >= 0; --k) { h[k] = Qp[k] * pw; pw *= dx; }
+        for (int k = 1; k <= KT; ++k) { fs *= (double)k * inv_sc; Gt[k] = rows[k - 1] * fs; }
     }
-    double sc_n = w;
-    constexpr int NLOW = (KT < M2) ? KT : M2;
+    const double dxs = dx * inv_sc;
 #pragma unroll
-    for (int n = 0; n < NLOW; ++n) {
-        double v0 = 0.0, v1 = 0.0;
+    for (int n = 0; n < M2; ++n) {
+        row[n] = Gt[0];
 #pragma unroll
-        for (int k = 0; k <= KT; ++k) {
-            if (k <= n) { if (k % 2 == 0) v0 = fma(Qp[k], E[k], v0); else v1 = fma(Qp[k], E[k], v1); }
-        }
-        row[n] = sc_n * (v0 + v1);
-        sc_n *= inv_sc;
-#pragma unroll
-        for (int k = KT; k >= 1; --k) E[k] = fma(dx, E[k], E[k - 1]);
-        E[0] *= dx;
-#pragma unroll
-        for (int jj = 0; jj < KT; ++jj) h[jj] += h[jj + 1];
-    }
-    double P = sc_n;                 // w inv_sc^KT (dx inv_sc)^(n-KT)
-    const double step = dx * inv_sc;
-#pragma unroll
-    for (int n = NLOW; n < M2; ++n) {
-        row[n] = P * h[0];
-        P *= step;
-#pragma unroll
-        for (int jj = 0; jj < KT; ++jj) h[jj] += h[jj + 1];
+        for (int jj = 0; jj < KT; ++jj) Gt[jj] = fma(dxs, Gt[jj], Gt[jj + 1]);
+        Gt[KT] *= dxs;
     }
 }
 
