@@ -682,18 +682,19 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
                             }
                         }
                     } else {
-                        // normal closure: E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n-1) v E_{n-2}   (moments.py:70-74)
-                        const double m = mu - c;
-                        double e2 = 1.0, e1 = m, sc_n = w;
-                        row[0] = sc_n;
-                        sc_n *= inv_sc;
-                        row[1] = sc_n * m;
+                        // normal closure: E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n-1) v E_{n-2}   (moments.py:70-74), run on
+                        // F_n = w E_n / s^n directly: F_n = (m/s) F_{n-1} + (n-1) (v/s^2) F_{n-2}, F_0 = w
+                        const double ms = (mu - c) * inv_sc, vs = var * inv_sc * inv_sc;
+                        double f2 = w, f1 = w * ms, vn = vs;
+                        row[0] = f2;
+                        row[1] = f1;
+#pragma unroll
                         for (int n = 2; n < M2; ++n) {
-                            const double e = fma(m, e1, (double)(n - 1) * var * e2);
-                            sc_n *= inv_sc;
-                            row[n] = sc_n * e;
-                            e2 = e1;
-                            e1 = e;
+                            const double f = fma(ms, f1, vn * f2);
+                            row[n] = f;
+                            vn += vs;
+                            f2 = f1;
+                            f1 = f;
                         }
                     }
                 } else {
