@@ -204,14 +204,20 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     // -- Cholesky (quadratures.py:154) or LDL^T completion (mfs/utils.py:495-538)
     if (!stable) {
         // Register-resident front end on ONE wave, no barriers: lane i (< S) owns row i of G -> L; lane c (< 2S) owns
-        // column c of [H_0 | H_1].  Column step j broadcasts L[j][k] with v_readlane (the filter is alone in its
-        // wave, so the source lane is wave-uniform) and uses each broadcast twice: for the Cholesky dot products
+        // column c of [H_0 | H_1].  Column step j needs L[j][k] in every lane, twice: for the Cholesky dot products
         // and for the forward substitution X = R^-1 [H_0 | H_1] (quadratures.py:156-161, inner solve) fused into
-        // the same sweep.  The outer solve K^T = R^-1 X^T reuses the rows of L after a transpose through the K tiles.
+        // the same sweep.  As soon as column k of L is final, gfx950's lane swaps (v_permlane16_swap / 32_swap on
+        // (v, copy of v)) spread DPP row 0 and DPP row 1 of it over all four rows of the wave, once; every later use
+        // is then the row_newbcast operand of the multiply-add itself (one instruction per term instead of two
+        // v_readlane + a multiply-add).  The outer solve K^T = R^-1 X^T reuses them after a transpose through the K tiles.
         if (tid < 64) {
             const int li = (tid < S) ? tid : S - 1;
             const int hc = (tid < 2 * S) ? tid : 0, hm = hc / S, hj = hc - hm * S;
-            double Lr[S], xc[S], rinv_u[S];
+            static_assert(S <= 32, "rows of L live in DPP rows 0 and 1");
+            constexpr int S0 = (S < 16) ? S : 16;     // columns whose entries are needed from DPP row 0 (rows j < 16)
+            double Lr[S], xc[S];
+            double* rinv_lds = Sm + L::oRed;          // 1 / L_jj, parked in LDS between the two solves (registers are short)
+            double D0[S0], D1[(S > 16) ? S : 1];      // column k of L: DPP row 0 / DPP row 1 of it in all four rows
             static_for<0, S>([&](auto Jc) { Lr[Jc] = A[li * LD + Jc]; xc[Jc] = K[hm * NP * LD + Jc * LD + hj]; });
             bool bad = false;
             static_for<0, S>([&](auto Jc) {
@@ -219,16 +225,21 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 double s = Lr[j], xa = xc[j];
                 static_for<0, j>([&](auto Kc) {
                     constexpr int k = Kc;
-                    const double bc = bcast<64, j>(Lr[k]);
-                    s = fma(-Lr[k], bc, s);
-                    xa = fma(-bc, xc[k], xa);
+                    if constexpr (j < 16) { fnma_bcast<16, j>(s, Lr[k], D0[k]); fnma_bcast<16, j>(xa, xc[k], D0[k]); }
+                    else { fnma_bcast<16, j - 16>(s, Lr[k], D1[k]); fnma_bcast<16, j - 16>(xa, xc[k], D1[k]); }
                 });
                 const double pj = bcast<64, j>(s);
                 bad |= !(pj > 0.0);
                 const double rinv = rsq_nr(pj);
-                rinv_u[j] = rinv;
+                if (tid == 0) rinv_lds[j] = rinv;
                 Lr[j] = s * rinv;       // row j itself gets sqrt(piv) = piv * rinv
                 xc[j] = xa * rinv;
+                if constexpr (j + 1 < S) {   // column j is final: spread its two DPP rows over the wave
+                    double ev, od, lo, up;
+                    row_dup(Lr[j], ev, od);
+                    if constexpr (j < S0) { half_dup(ev, lo, up); D0[j] = lo; }
+                    if constexpr (S > 16) { half_dup(od, lo, up); D1[j] = lo; }
+                }
             });
             if (tid == 0 && bad) flags[0] = 1.0;
             // transpose X through the K tiles: column hc of X_m -> K_m[:, hj]
@@ -242,9 +253,10 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 double acc = yr[i];
                 static_for<0, i>([&](auto Kc) {
                     constexpr int k = Kc;
-                    acc = fma(-bcast<64, i>(Lr[k]), yr[k], acc);
+                    if constexpr (i < 16) fnma_bcast<16, i>(acc, yr[k], D0[k]);
+                    else fnma_bcast<16, i - 16>(acc, yr[k], D1[k]);
                 });
-                yr[i] = acc * rinv_u[i];
+                yr[i] = acc * rinv_lds[i];
             });
             wave_sync();
             static_for<0, S>([&](auto Jc) { if (tid < 2 * S) K[hm * NP * LD + hj * LD + Jc] = yr[Jc]; });
