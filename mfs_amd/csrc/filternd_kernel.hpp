@@ -741,25 +741,33 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                         });
                     }
                 } else {
-                    // update (either transition kind): prod_k (x_k - c_k)^{n_k} times the likelihood, in table order
-                    for (int base = 0; base < R; base += 256) {
-                        double wA, pxA0[P], pxA1[P], bt[16];
+                    // update (either transition kind): prod_k (x_k - c_k)^{n_k} times the likelihood, in table order; two
+                    // nodes per thread share each row reduction
+                    for (int base = 0; base < R; base += 512) {
+                        double wA, wB, pxA0[P], pxA1[P], pxB0[P], pxB1[P], bt[16];
                         {
-                            const int eA = base + tid;
-                            const bool okA = eA < R;
+                            const int eA = base + tid, eB = base + 256 + tid;
+                            const bool okA = eA < R, okB = eB < R;
                             const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
+                            const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
                             wA = okA ? W[eA] : 0.0;
+                            wB = okB ? W[eB] : 0.0;
                             const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
-                            pxA0[0] = pxA1[0] = 1.0;
+                            const double xB0 = fma(lam[iB0], qs0, qm0), xB1 = fma(lam[NP + iB1], qs1, qm1);
+                            pxA0[0] = pxA1[0] = pxB0[0] = pxB1[0] = 1.0;
 #pragma unroll
-                            for (int p = 1; p < P; ++p) { pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1); }
+                            for (int p = 1; p < P; ++p) {
+                                pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1);
+                                pxB0[p] = pxB0[p - 1] * (xB0 - c0); pxB1[p] = pxB1[p - 1] * (xB1 - c1);
+                            }
                             wA *= likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
+                            wB *= likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? xB0 : xB1);
                         }
                         static_for<0, 2 * N>([&](auto Sc) {
                             constexpr int sd = Sc;
                             static_for<0, sd + 1>([&](auto N0c) {
                                 constexpr int n0 = N0c, n1 = sd - n0, zi = sd * (sd + 1) / 2 + n0;
-                                bt[zi % 16] = wA * (pxA0[n0] * pxA1[n1]);
+                                bt[zi % 16] = fma(wA, pxA0[n0] * pxA1[n1], wB * (pxB0[n0] * pxB1[n1]));
                                 if constexpr (zi % 16 == 15 || zi == Z - 1) {
                                     if constexpr (zi % 16 != 15) static_for<zi % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
                                     const double v = row_reduce16(bt, lane16);
