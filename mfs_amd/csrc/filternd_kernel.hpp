@@ -330,31 +330,40 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     //    quadratically from there (2-3 sweeps instead of 8-9); V then accumulates on top of V_prev.  The tile of the
     //    Cholesky factor is free by now and serves as the temporary.
     if (warm) {
-        for (int m = 0; m < 2; ++m) {
+        // both matrices in the same two stages (the weight tile, free until the end of the rule, is the second scratch)
+        double* A1 = Sm + L::oW;   // [S][S]
+        for (int e = tid; e < 2 * S * S; e += nthr) {   // A_m = K_m V_m
+            const int m = e / (S * S), f = e - m * S * S, i = f / S, j = f - i * S;
+            const double* Kk = K + m * NP * LD;
+            const double* Vk = V + m * NP * LD;
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) acc = fma(Kk[i * LD + k], Vk[k * LD + j], acc);
+            if (m == 0) A[i * LD + j] = acc; else A1[i * S + j] = acc;
+        }
+        __syncthreads();
+        constexpr int TRI = S * (S + 1) / 2;
+        for (int e = tid; e < 2 * TRI; e += nthr) {     // K_m = V_m^T A_m on the lower triangle, symmetrised on the fly
+            const int m = e / TRI, t = e - m * TRI;
+            int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            i += ((i + 1) * (i + 2) / 2 <= t) ? 1 : 0;
+            i -= (i * (i + 1) / 2 > t) ? 1 : 0;
+            const int j = t - i * (i + 1) / 2;
             double* Kk = K + m * NP * LD;
             const double* Vk = V + m * NP * LD;
-            for (int e = tid; e < S * S; e += nthr) {   // A = K V
-                const int i = e / S, j = e - i * S;
-                double acc = 0.0;
-                for (int k = 0; k < S; ++k) acc = fma(Kk[i * LD + k], Vk[k * LD + j], acc);
-                A[i * LD + j] = acc;
+            const double* Am = (m == 0) ? A : A1;
+            const int lda = (m == 0) ? LD : S;
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                a1 = fma(Vk[k * LD + i], Am[k * lda + j], a1);
+                a2 = fma(Vk[k * LD + j], Am[k * lda + i], a2);
             }
-            __syncthreads();
-            for (int e = tid; e < S * S; e += nthr) {   // K = V^T A, symmetrised on the fly
-                const int i = e / S, j = e - i * S;
-                if (i >= j) {
-                    double a1 = 0.0, a2 = 0.0;
-                    for (int k = 0; k < S; ++k) {
-                        a1 = fma(Vk[k * LD + i], A[k * LD + j], a1);
-                        a2 = fma(Vk[k * LD + j], A[k * LD + i], a2);
-                    }
-                    const double v = 0.5 * (a1 + a2);
-                    Kk[i * LD + j] = v;
-                    Kk[j * LD + i] = v;
-                }
-            }
-            __syncthreads();
+            const double v = 0.5 * (a1 + a2);
+            Kk[i * LD + j] = v;
+            Kk[j * LD + i] = v;
         }
+        __syncthreads();
     }
 
     ND_STAMP(3);
