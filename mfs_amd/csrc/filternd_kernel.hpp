@@ -370,6 +370,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     // -- cyclic Jacobi on both matrices with eigenvectors (quadratures.py:163)
     double prev_off = 1.79e308;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+        // (after a warm start the first two sweeps are always needed -- the off-diagonal mass goes 1e-6 -> 1e-12 -> 1e-24
+        //  of the diagonal's -- so the convergence test, a pass over both matrices and two barriers, starts at the third)
+        if (!(warm && sweep < 2)) {
         double off = 0.0, dia = 0.0;
         for (int e = tid; e < 2 * S * S; e += nthr) {
             const double* Kk = K + (e / (S * S)) * NP * LD;
@@ -388,6 +391,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         if (!(off > 1e-31 * dia)) break;
         if (off < 1e-26 * dia && off > 0.25 * prev_off) break;
         prev_off = off;
+        }
 #ifdef MFS_ND_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[8] += 1;
 #endif
