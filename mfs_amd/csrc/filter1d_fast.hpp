@@ -1,7 +1,9 @@
 // filter1d_fast.hpp -- register-resident 1-D moment-filter step for gfx950 (the default path; the LDS-tile kernel in
 // filter1d_kernel.hpp remains as the "dense" path: stable=True and cross-checks).
 //
-// A filter is owned by G lanes (G = 16: one DPP row; 32; 64), lane l holding row l of the problem in VGPRs.
+// A filter is owned by G lanes (G = 8: half a DPP row; 16: one row; 32: two rows; 64), lane l holding row l of the
+// problem in VGPRs.  Cross-lane traffic is the DPP operand of the arithmetic instruction wherever the ISA allows it
+// (v_fmac_f64_dpp row_newbcast), bank-masked moves for G = 8, gfx950 lane swaps (v_permlane16/32_swap) for G >= 32.
 //
 // Quadrature (reference mfs/one_dim/quadtures.py:122-133), restructured around two identities of Hankel moment
 // matrices -- same mathematics, O(N^3/6 + N^2) work instead of O(12 N^3):
@@ -15,9 +17,12 @@
 //         K_jj = sub_j / piv_j - sub_{j-1} / piv_{j-1},      K_{j+1,j}^2 = piv_{j+1} / piv_j.
 //     The second triangular solve collapses to these ratios.  (quadtures.py:129, outer triangular_solve)
 //   * Golub-Welsch eigensolve (quadtures.py:131-133) on the tridiagonal: lane k isolates eigenvalue k with Sturm
-//     counts and polishes it with safeguarded Newton steps on the characteristic polynomial (all lanes run the same
-//     three-term recurrence on their own abscissa: no cross-lane traffic); the squared first eigenvector components
-//     are w_k = 1 / sum_j c_j p_j(lambda_k)^2 with c_j = piv_0 / piv_j.
+//     counts and reaches it with Laguerre's iteration on the characteristic polynomial (all lanes run the same
+//     three-term recurrence on their own abscissa: no cross-lane traffic), started from the rule the filter already
+//     knows (see the kernel); the squared first eigenvector components are w_k = 1 / sum_j c_j p_j(lambda_k)^2 with
+//     c_j = piv_0 / piv_j.
+//   * The Cholesky factor itself is never formed: only its pivots and sub-diagonal enter, so the elimination runs in
+//     square-root-free (LDL^T) form.
 //
 // In exact arithmetic this equals the reference's dense route; in fp64 the two differ by the rounding-level
 // off-tridiagonal noise of the dense K, which is the same size as the difference between any two dense

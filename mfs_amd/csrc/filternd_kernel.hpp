@@ -4,22 +4,25 @@
 // mfs/multi_dims/quadratures.py:120-178 (moment_quadrature_nd), mfs/multi_dims/moments.py:414-479 (TME transition).
 //
 // One filter per 256-thread workgroup (4 waves); the k-loop runs inside the kernel.  Per half step:
-//   quadrature_nd  G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; one Cholesky; two pairs
-//                  of triangular solves; both K_k diagonalised TOGETHER by cyclic Jacobi (round-robin tournament,
-//                  2x2 blocks: 2 (s/2)^2 blocks <= 256 threads at s = 21) with the eigenvector matrices accumulated;
+//   quadrature_nd  G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; Cholesky and both triangular
+//                  solves on one wave in registers (columns of L reach the other lanes as DPP operands after a lane-swap
+//                  duplication); K_k' = V_prev^T K_k V_prev warm start; both K_k diagonalised TOGETHER by cyclic Jacobi
+//                  (round-robin tournament from an LDS index table, one item = a 2x2 block of K_m + two eigenvector
+//                  row-pairs: 2 (s/2)^2 items <= 256 threads at s = 21) with the eigenvector matrices accumulated;
 //                  s^2 tensor-product nodes with weights <v0_i, v1_j> v0_i[0] v1_j[0]      (quadratures.py:165-170)
-//   predict        per node, every moment sum_kappa Q_kappa(x) prod_k n_k!/(n_k-kappa_k)! (x_k-c_k)^(n_k-kappa_k),
-//                  fully unrolled over the z moments and the fixed list of |kappa| <= 4 derivative terms, so that all
-//                  power / coefficient indices are compile-time constants (registers, no scratch)
-//   update         likelihood-weighted central / raw / scaled moments
-// and a wave-DPP + LDS tree reduction of the z per-thread accumulators.  No MFMA: s <= 28, fp64, sequential.
+//   predict        per node, sum_kappa Q_kappa(x) prod_k n_k!/(n_k-kappa_k)! (x_k-c_k)^(n_k-kappa_k) in its factorised
+//                  form (operator tables, moments.py:414-479) or the Stein recursion of a Normal closure (:257-411),
+//                  unrolled over the z moments so that every power / coefficient index is a compile-time constant
+//   update         likelihood-weighted raw / central / scaled-central moments
+// with the z moment sums formed 16 at a time through a transposing DPP row reduction into a [16 rows][z] LDS table.
+// No MFMA: s <= 28, fp64, sequential.
 #pragma once
 #include "filter1d_fast.hpp"
 
 namespace mfs {
 
 #ifdef MFS_ND_STAMPS
-// diagnostic build (scratch/nd_stamps.hip): cycles per phase, accumulated by thread 0 of block 0
+// diagnostic build (tools/diag/nd_stamps.hip): cycles per phase, accumulated by thread 0 of block 0
 __device__ unsigned long long g_nd_stamps[16];
 #define ND_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_nd_stamps[slot] += now_ - t_last_; t_last_ = now_; } } while (0)
 #define ND_STAMP_BEGIN unsigned long long t_last_ = clock64()
