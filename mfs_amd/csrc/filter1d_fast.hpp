@@ -60,8 +60,12 @@ __device__ __forceinline__ double bcast(double v) {
     } else if constexpr (G == 8) {
         // two filters share a DPP row: lane J of the lower half goes to banks 0-1, lane J of the upper half to banks 2-3
         // (bank_mask leaves the other lanes of the destination alone, so the second move completes the first)
-        double r = __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0x3, false);
-        r = __builtin_amdgcn_update_dpp(r, v, 0x150 + 8 + J, 0xf, 0xc, false);
+        // (written as asm: the builtin wants a defined pass-through value for the first move, a v_mov_b64 per broadcast,
+        // although every lane is written by one of the two; s_nop 1 covers the VALU-write -> DPP-read hazard)
+        double r;
+        asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3\n\t"
+            "v_mov_b64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xc"
+            : "=&v"(r) : "v"(v), "n"(J), "n"(8 + J));
         return r;
     } else if constexpr (G == 64) {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), J);
