@@ -56,7 +56,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <int G, int J>
 __device__ __forceinline__ double bcast(double v) {
     if constexpr (G == 16) {
-        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);  // v_mov_b64_dpp row_newbcast:J
+        // v_mov_b64_dpp row_newbcast:J.  bound_ctrl set (every lane has a source, so it changes nothing) lets the
+        // compiler drop the pass-through operand; without it each broadcast drags a v_mov_b64 0 along
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, true);
     } else if constexpr (G == 8) {
         // two filters share a DPP row: lane J of the lower half goes to banks 0-1, lane J of the upper half to banks 2-3
         // (bank_mask leaves the other lanes of the destination alone, so the second move completes the first)
@@ -91,6 +93,18 @@ __device__ __forceinline__ void fnma_bcast(double& acc, const double u, const do
             : "+v"(acc) : "v"(v), "v"(u), "n"(J));
     } else {   // (a bank-masked v_fmac_f64_dpp pair for G = 8 does not keep the masked lanes' accumulator: tools/diag/dpp_bank_test.hip)
         acc = fma(-u, bcast<G, J>(v), acc);
+    }
+}
+
+// acc = -u * (v of lane J of the group): the first term of a partial sum.  Where the broadcast is a separate move this
+// is a plain multiplication; v_mul_f64 has no DPP form, so 16-lane groups keep the multiply-add into a zero.
+template <int G, int J>
+__device__ __forceinline__ void nmul_bcast(double& acc, const double u, const double v) {
+    if constexpr (G == 16) {
+        acc = 0.0;
+        fnma_bcast<G, J>(acc, u, v);
+    } else {
+        acc = -u * bcast<G, J>(v);
     }
 }
 
@@ -380,7 +394,10 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         double s = g[j], s2 = 0.0;   // two partial sums: the dot product is not one dependent chain
         static_for<0, j>([&](auto Kc) {
             constexpr int k = Kc;
-            if constexpr (G == 32) {
+            constexpr int k0 = ((j - 1) % 2 == 1) ? 0 : 1;   // first term of s2
+            if constexpr (G != 32 && k == k0) {
+                nmul_bcast<G, j>(s2, Ur[k], Vr[k]);
+            } else if constexpr (G == 32) {
                 if constexpr (j < 16) {
                     if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<16, j>(s, Ur[k], VrA[k]); else fnma_bcast<16, j>(s2, Ur[k], VrA[k]);
                 } else {
@@ -579,7 +596,11 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
         const double* src = a.coef + (a.coef_batched ? (size_t)b * a.n_rows * J1 : 0);
         for (int e = l; e < ((a.degree + 4) & ~3) * kCoefRows; e += G) {   // [row][degree] in HBM -> [degree][row] in LDS,
             const int j = e / kCoefRows, r = e - j * kCoefRows;             // zero-padded in both directions
-            S[L::oCoef + e] = (r < a.n_rows && j < J1) ? src[r * J1 + j] : 0.0;
+            // operator tables: the variance row (source row n_terms) always lands in LDS row MFS_MAX_TERMS and the rows
+            // between stay zero, so the time loop reads both from fixed registers whatever the number of terms
+            int sr = r;
+            if (a.trans_kind == MFS_TRANS_OPERATOR) sr = (r == MFS_MAX_TERMS) ? a.n_terms : (r < a.n_terms) ? r : a.n_rows;
+            S[L::oCoef + e] = (sr < a.n_rows && j < J1) ? src[sr * J1 + j] : 0.0;
         }
         const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
         for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + e] = (e < a.n_lik) ? ls[e] : 0.0;
@@ -658,9 +679,7 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
                     double mu, var;
                     if (a.trans_kind == MFS_TRANS_OPERATOR) {
                         mu = x + rows[0];
-                        var = 0.0;
-#pragma unroll
-                        for (int k = 0; k <= MFS_MAX_TERMS; ++k) var = (k == a.n_terms) ? rows[k] : var;
+                        var = rows[MFS_MAX_TERMS];
                     } else {
                         mu = fma(a.mean_x_coef, x, rows[0]);
                         var = rows[1];
@@ -682,13 +701,8 @@ __global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_ker
                             case 2: operator_moments<2, M2>(rows, x - c, w, inv_sc, node, row); break;
                             case 4: operator_moments<4, M2>(rows, x - c, w, inv_sc, node, row); break;
                             case 6: operator_moments<6, M2>(rows, x - c, w, inv_sc, node, row); break;
-                            default: {  // any other term count: zero the rows that are not operator terms (row K = variance)
-                                double rq[MFS_MAX_TERMS + 1];
-#pragma unroll
-                                for (int k = 0; k <= MFS_MAX_TERMS; ++k) rq[k] = (k < a.n_terms) ? rows[k] : 0.0;
-                                operator_moments<MFS_MAX_TERMS, M2>(rq, x - c, w, inv_sc, node, row);
-                                break;
-                            }
+                            // any other term count: the rows past the last term are zero in the LDS table
+                            default: operator_moments<MFS_MAX_TERMS, M2>(rows, x - c, w, inv_sc, node, row); break;
                         }
                     } else {
                         // normal closure: E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n-1) v E_{n-2}   (moments.py:70-74), run on
