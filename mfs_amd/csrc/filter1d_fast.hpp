@@ -127,8 +127,9 @@ __device__ __forceinline__ double vmax_f64(const double a, const double b) {
 // ds_bpermute round trips through the LDS crossbar.
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // (bound_ctrl set: these patterns give every lane a source, and with it the compiler needs no pass-through value)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -164,7 +165,7 @@ __device__ __forceinline__ double gsum(double v) {
         v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
         v += dpp_move<0x141>(v);  // row_half_mirror
         v += dpp_move<0x140>(v);  // row_mirror
-        return __builtin_amdgcn_update_dpp(0.0, v, 0x150, 0xf, 0xf, false);  // lane 0's sum to every lane
+        return __builtin_amdgcn_update_dpp(0.0, v, 0x150, 0xf, 0xf, true);  // lane 0's sum to every lane
     } else if constexpr (G == 8) {
         v += dpp_move<0xB1>(v);
         v += dpp_move<0x4E>(v);
