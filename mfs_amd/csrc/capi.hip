@@ -16,6 +16,7 @@
 namespace mfs {
 KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
 Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
+Filter1dFastLaunch g_fast_filter_wide[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
@@ -94,6 +95,7 @@ struct mfs_plan_1d {
     mfs_model_1d model;  // device pointers inside
     int mode, N, T, B, stable, chunk, device;
     int slot, G, fpb, grid, lds_bytes, lds_doubles;
+    bool single_wave_per_simd = false;
     double* d_coef = nullptr;
     double* d_lik = nullptr;
     double* c_mom = nullptr;
@@ -210,6 +212,11 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     p->lds_doubles = ke.lds_doubles_per_filter;
     if (slot >= 3) p->lds_doubles += ((model->degree + 4) & ~3) * 10;  // fast path: + model table [ceil4(degree + 1)][kCoefRows]
     p->lds_bytes = p->fpb * p->lds_doubles * 8;
+    {   // blocks of the fast path are single waves: with at most one per SIMD the wide-register variant costs nothing
+        hipDeviceProp_t prop;
+        p->single_wave_per_simd = (slot >= 3 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+                                   p->grid <= 4 * prop.multiProcessorCount);
+    }
 
     const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * model->n_rows * (model->degree + 1);
     const size_t nlik = (size_t)(model->lik_batched ? B : 1) * model->n_lik;
@@ -247,7 +254,10 @@ int mfs_plan_1d_geometry(const mfs_plan_1d* p, int* lanes_per_filter, int* filte
 }
 
 static hipError_t launch_filter(mfs_plan_1d* p, const mfs::Filter1dArgs& a, hipStream_t s) {
-    if (p->slot >= 3) return mfs::g_fast_filter[p->N][p->slot - 3](a, p->grid, p->lds_doubles, s);
+    if (p->slot >= 3) {
+        const mfs::Filter1dFastLaunch wide = mfs::g_fast_filter_wide[p->N][p->slot - 3];
+        return (wide && p->single_wave_per_simd ? wide : mfs::g_fast_filter[p->N][p->slot - 3])(a, p->grid, p->lds_doubles, s);
+    }
     return mfs::g_table[p->N][p->slot].filter(a, p->grid, p->lds_bytes, s);
 }
 

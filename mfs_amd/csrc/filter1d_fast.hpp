@@ -575,8 +575,12 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 // two waves per SIMD is the register budget that holds the unrolled state without scratch up to N = 16 (asking for
 // three at N <= 8 spilled 24 dwords per lane and measured 12 % slower on config 4; four was 30 % slower); the 32- and
 // 64-lane instantiations (N > 16) take the whole register file of a SIMD lane: their state does not fit in 256 VGPRs
-template <int N, int G, int WPB>
-__global__ __launch_bounds__(WPB * 64, (N <= 16) ? 2 : 1) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
+// OCC = waves per SIMD the register budget is sized for.  Two (256 VGPRs) is the default for N <= 16; the orders whose
+// time loop does not fit in 256 registers (N = 14..16: a few pointers spill to scratch, and every reload is a
+// s_waitcnt vmcnt(0) in the step) also exist with OCC = 1 (512 registers), which the plan picks when the batch puts no
+// more than one wave on a SIMD anyway.
+template <int N, int G, int WPB, int OCC>
+__global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
     using L = FastTile<N, G>;
     constexpr int M2 = L::M2, TLD = L::TLD;
     constexpr int FPW = 64 / G;

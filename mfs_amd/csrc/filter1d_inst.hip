@@ -10,6 +10,7 @@ namespace mfs {
 
 extern KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // defined in capi.hip
 extern Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
+extern Filter1dFastLaunch g_fast_filter_wide[MFS_MAX_N + 1][4];  // nullptr where the default budget does not spill
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 extern Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 
@@ -60,16 +61,16 @@ void reg(int gi) {
 }
 
 // ---- fast (register-resident) path: single-wave workgroups, LDS = filters per wave x (fixed + model table)
-template <int N, int G>
+template <int N, int G, int OCC>
 hipError_t launch_filter_fast(const Filter1dArgs& a, int grid, int lds_doubles, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter1d_fast_kernel<N, G, 1>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter1d_fast_kernel<N, G, 1, OCC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((filter1d_fast_kernel<N, G, 1>), dim3(grid), dim3(64), (64 / G) * lds_doubles * 8, s, a,
+    hipLaunchKernelGGL((filter1d_fast_kernel<N, G, 1, OCC>), dim3(grid), dim3(64), (64 / G) * lds_doubles * 8, s, a,
                        lds_doubles);
     return hipGetLastError();
 }
@@ -90,7 +91,10 @@ template <int N, int G>
 void reg_fast(int gi) {
     g_cf[N][gi] = &launch_cf_fast<N, G>;
     KernelEntry& e = g_table[N][3 + gi];  // gi: 0..2 = G 16 / 32 / 64, 3 = G 8
-    g_fast_filter[N][gi] = &launch_filter_fast<N, G>;
+    constexpr int occ = (N <= 16) ? 2 : 1;
+    g_fast_filter[N][gi] = &launch_filter_fast<N, G, occ>;
+    // one-wave-per-SIMD register budget for the orders that spill at two (their default lane count only)
+    if constexpr (N >= 14 && N <= 16 && G == ((N + 1 <= 16) ? 16 : 32)) g_fast_filter_wide[N][gi] = &launch_filter_fast<N, G, 1>;
     e.filter = nullptr;
     e.quad = &launch_quad_fast<N, G>;
     e.lds_doubles_per_filter = FastTile<N, G>::fixedDoubles;
