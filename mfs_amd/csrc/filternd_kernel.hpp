@@ -24,6 +24,7 @@ namespace mfs {
 #ifdef MFS_ND_STAMPS
 // diagnostic build (tools/diag/nd_stamps.hip): cycles per phase, accumulated by thread 0 of block 0
 __device__ unsigned long long g_nd_stamps[16];
+__device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / dia), clamped]: Jacobi convergence tests of block 0
 #define ND_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_nd_stamps[slot] += now_ - t_last_; t_last_ = now_; } } while (0)
 #define ND_STAMP_BEGIN unsigned long long t_last_ = clock64()
 #else
@@ -55,6 +56,16 @@ struct FilterNdArgs {
 // derivative multi-indices kappa with 1 <= |kappa| <= 4, graded-lex order (the order the host fills `coef` in)
 constexpr int kNdTerms = 14;
 constexpr int kNdRows = 16;
+#ifndef MFS_ND_JACOBI_TOL
+#define MFS_ND_JACOBI_TOL 1e-31
+#endif
+// off-diagonal / diagonal mass (squared Frobenius norms) at which the Jacobi sweeps stop
+constexpr double kNdJacobiTol = MFS_ND_JACOBI_TOL;
+#ifndef MFS_ND_FINISH_X2
+#define MFS_ND_FINISH_X2 1e-14
+#endif
+// squared Frobenius size of the first-order eigenvector correction below which it replaces further sweeps (0: never)
+constexpr double kNdFinishX2 = MFS_ND_FINISH_X2;
 constexpr int kNdMaxD = 6;
 __device__ constexpr int kKap0[kNdTerms] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
 __device__ constexpr int kKap1[kNdTerms] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
@@ -376,23 +387,78 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         // (after a warm start the first two sweeps are always needed -- the off-diagonal mass goes 1e-6 -> 1e-12 -> 1e-24
         //  of the diagonal's -- so the convergence test, a pass over both matrices and two barriers, starts at the third)
         if (!(warm && sweep < 2)) {
-        double off = 0.0, dia = 0.0;
+        // off / dia: off-diagonal and diagonal mass; xsq = sum_{i != j} (K_ij / (K_jj - K_ii))^2, the squared size of the
+        // first-order eigenvector correction (below)
+        double off = 0.0, dia = 0.0, xsq = 0.0;
         for (int e = tid; e < 2 * S * S; e += nthr) {
             const double* Kk = K + (e / (S * S)) * NP * LD;
             const int f = e % (S * S), i = f / S, j = f - i * S;
             const double v = Kk[i * LD + j];
-            if (i == j) dia += v * v; else off += v * v;
+            const double dd = Kk[j * (LD + 1)] - Kk[i * (LD + 1)];
+            if (i == j) dia += v * v;
+            else { off += v * v; xsq += (v * v) * __builtin_amdgcn_rcp(dd * dd); }
         }
         off = wave_sum64(off);
         dia = wave_sum64(dia);
+        xsq = wave_sum64(xsq);
         __syncthreads();  // previous readers of the scratch slots are done
-        if ((tid & 63) == 0) { Sm[L::oRed + 2 * (tid >> 6)] = off; Sm[L::oRed + 2 * (tid >> 6) + 1] = dia; }
+        if ((tid & 63) == 0) {
+            Sm[L::oRed + 3 * (tid >> 6)] = off; Sm[L::oRed + 3 * (tid >> 6) + 1] = dia; Sm[L::oRed + 3 * (tid >> 6) + 2] = xsq;
+        }
         __syncthreads();
-        off = Sm[L::oRed] + Sm[L::oRed + 2] + Sm[L::oRed + 4] + Sm[L::oRed + 6];
-        dia = Sm[L::oRed + 1] + Sm[L::oRed + 3] + Sm[L::oRed + 5] + Sm[L::oRed + 7];
+        off = Sm[L::oRed] + Sm[L::oRed + 3] + Sm[L::oRed + 6] + Sm[L::oRed + 9];
+        dia = Sm[L::oRed + 1] + Sm[L::oRed + 4] + Sm[L::oRed + 7] + Sm[L::oRed + 10];
+        xsq = Sm[L::oRed + 2] + Sm[L::oRed + 5] + Sm[L::oRed + 8] + Sm[L::oRed + 11];
+#ifdef MFS_ND_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            int bin = (off > 0.0 && dia > 0.0) ? (int)(-log10(off / dia)) : 39;
+            bin = bin < 0 ? 0 : bin > 39 ? 39 : bin;
+            g_nd_hist[sweep < 8 ? sweep : 7][bin] += 1;
+        }
+#endif
         if (!finite(off + dia)) { if (tid == 0) flags[0] = 1.0; break; }
-        if (!(off > 1e-31 * dia)) break;
+        if (!(off > kNdJacobiTol * dia)) break;
         if (off < 1e-26 * dia && off > 0.25 * prev_off) break;
+        if (xsq <= kNdFinishX2) {
+            // Nearly diagonal, K = D + E with every |E_ij / (d_j - d_i)| < 1e-7: the eigenvectors are the columns of
+            // I + X, X_ij = E_ij / (d_j - d_i) (antisymmetric, so I + X is orthogonal up to X^T X <= 1e-14), the
+            // eigenvalues d_j + sum_i E_ij X_ij -- as accurate as one more sweep at the price of one S x S x S product
+            // per matrix instead of S - 1 rounds of rotations (close eigenvalues make X large and take the sweep)
+            for (int e = tid; e < 2 * S * S; e += nthr) {      // X over the off-diagonal of K (the diagonal stays)
+                double* Kk = K + (e / (S * S)) * NP * LD;
+                const int f = e % (S * S), i = f / S, j = f - i * S;
+                if (i != j) Kk[i * LD + j] = Kk[i * LD + j] / (Kk[j * (LD + 1)] - Kk[i * (LD + 1)]);
+            }
+            __syncthreads();
+            double* T1 = Sm + L::oW;
+            for (int e = tid; e < 2 * S * S; e += nthr) {      // T_m = V_m X_m
+                const int m = e / (S * S), f = e - m * S * S, k = f / S, j = f - k * S;
+                const double* Kk = K + m * NP * LD;
+                const double* Vk = V + m * NP * LD;
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < S; ++i) acc = fma(Vk[k * LD + i], (i == j) ? 0.0 : Kk[i * LD + j], acc);
+                if (m == 0) A[k * LD + j] = acc; else T1[k * S + j] = acc;
+            }
+            for (int e = tid; e < 2 * S; e += nthr) {          // second-order eigenvalues, parked in the rotation records
+                const int m = e / S, j = e - m * S;
+                const double* Kk = K + m * NP * LD;
+                const double dj = Kk[j * (LD + 1)];
+                double acc = dj;
+                for (int i = 0; i < S; ++i) {
+                    const double x = (i == j) ? 0.0 : Kk[i * LD + j];
+                    acc = fma((dj - Kk[i * (LD + 1)]) * x, x, acc);
+                }
+                cs[e] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < 2 * S * S; e += nthr) {
+                const int m = e / (S * S), f = e - m * S * S, k = f / S, j = f - k * S;
+                V[m * NP * LD + k * LD + j] += (m == 0) ? A[k * LD + j] : T1[k * S + j];
+            }
+            for (int e = tid; e < 2 * S; e += nthr) K[(e / S) * NP * LD + (e % S) * (LD + 1)] = cs[e];
+            break;
+        }
         prev_off = off;
         }
 #ifdef MFS_ND_STAMPS

@@ -30,6 +30,14 @@ int main(int argc, char** argv) {
     double tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
     printf("half-steps %llu, sweeps %llu (%.2f per quadrature)\n", st[9], st[8], (double)st[8] / st[9]);
     for (int i = 0; i < 8; ++i) printf("%-24s %10.0f cycles per half-step  %5.1f %%\n", names[i], (double)st[i] / st[9], 100.0 * st[i] / tot);
+    unsigned long long hist[8][40]; hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_nd_hist), sizeof(hist));
+    for (int t = 0; t < 8; ++t) {
+        unsigned long long n = 0; for (int k = 0; k < 40; ++k) n += hist[t][k];
+        if (!n) continue;
+        printf("convergence test before sweep %d (%llu tests): -log10(off/dia) histogram:", t, n);
+        for (int k = 0; k < 40; ++k) if (hist[t][k]) printf(" %d:%llu", k, hist[t][k]);
+        printf("\n");
+    }
     std::vector<double> nell(B); hipMemcpy(nell.data(), dnell, B * 8, hipMemcpyDeviceToHost); printf("nell[0] = %.10f\n", nell[0]);
     return 0;
 }
