@@ -383,6 +383,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     ND_STAMP(3);
     // -- cyclic Jacobi on both matrices with eigenvectors (quadratures.py:163)
     double prev_off = 1.79e308;
+    const int kw_slot = (tid < 2 * HP * HP) ? tid % (HP * HP) : 0;
+    unsigned kw_next = 0;
+    if constexpr (L::kTables) kw_next = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[kw_slot];
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
         // (after a warm start the first two sweeps are always needed -- the off-diagonal mass goes 1e-6 -> 1e-12 -> 1e-24
         //  of the diagonal's -- so the convergence test, a pass over both matrices and two barriers, starts at the third)
@@ -467,8 +470,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
 
         for (int r = 0; r < NP - 1; ++r) {
             // this round's index word is fetched and unpacked before the rotations / the barrier, off the update's path
-            unsigned kw = 0;
-            if constexpr (L::kTables) kw = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[r * (HP * HP) + ((tid < 2 * HP * HP) ? tid % (HP * HP) : 0)];
+            // (the word itself was requested a round ago: its latency would otherwise stand in front of every other load)
+            const unsigned kw = kw_next;
+            if constexpr (L::kTables) kw_next = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[((r + 1 < NP - 1) ? r + 1 : 0) * (HP * HP) + kw_slot];
             const int p1 = kw & 255, p2 = (kw >> 8) & 255, q1 = (kw >> 16) & 255, q2 = kw >> 24;
             const int o11 = p1 * LD + q1, o12 = p1 * LD + q2, o21 = p2 * LD + q1, o22 = p2 * LD + q2;
             // ... and so are the block and the eigenvector entries the item will rotate: the rotations (below) only read
