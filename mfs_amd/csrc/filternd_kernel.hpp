@@ -642,9 +642,8 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     if (a.mode != MFS_MODE_RAW) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
     if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
     double* red = Sm + L::oRed;
-    if (tid == 0) red[16 * ZB] = 0.0;
+    if (tid == 0) { red[16 * ZB] = 0.0; Sm[L::oMisc + 5] = __hiloint2double(0, -1); }   // flag slot 1: step of the first non-finite result (an int in the low word)
     __syncthreads();
-    int first_nan = -1;
     bool dead = false;
     bool warm = false;
     const double qnan = __builtin_nan("");
@@ -832,7 +831,12 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     for (int base = 0; base < R; base += 512) {
                         double wA, wB, pxA0[P], pxA1[P], pxB0[P], pxB1[P], bt[16];
                         {
-                            const int eA = base + tid, eB = base + 256 + tid;
+                            // (the thread index is laundered so that these per-thread indices are recomputed every step:
+                            // hoisted out of the time loop they do not fit in the register budget and come back from
+                            // scratch -- a s_waitcnt vmcnt(0) each)
+                            int tv = tid;
+                            asm volatile("" : "+v"(tv));
+                            const int eA = base + tv, eB = base + 256 + tv;
                             const bool okA = eA < R, okB = eB < R;
                             const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
                             const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
 #endif
             }
             bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1) || !finite(scale0) || !finite(scale1);
-            if (bad) { dead = true; first_nan = t; }
+            if (bad) { dead = true; if (tid == 0) Sm[L::oMisc + 5] = __hiloint2double(0, t); }
         } else {
             for (int zi = tid; zi < Z; zi += 256) mom[zi] = qnan;
             mean0 = mean1 = nell = qnan;
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     }
     if (tid == 0) {
         a.out_nell[b] = nell;
-        if (a.out_first_nan) a.out_first_nan[b] = first_nan;
+        if (a.out_first_nan) a.out_first_nan[b] = __double2loint(Sm[L::oMisc + 5]);
     }
 }
 
