@@ -911,7 +911,11 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 __syncthreads();
                 bad = bad || poisoned || (red[16 * ZB] != 0.0);
                 __syncthreads();
-                if (tid == 0) red[16 * ZB] = 0.0;
+                if (tid == 0) {   // (a laundered zero: the hoisted constant was living in scratch)
+                    double zero = 0.0;
+                    asm volatile("" : "+v"(zero));
+                    red[16 * ZB] = zero;
+                }
                 ND_STAMP(7);
 #ifdef MFS_ND_STAMPS
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
@@ -927,7 +931,9 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         __syncthreads();
         if (a.out_mom) {
             double* dst = a.out_mom + ((size_t)b * a.T + t) * Z;
-            for (int zi = tid; zi < Z; zi += 256) dst[zi] = mom[zi];
+            int tz = tid;                       // (laundered, as above: no per-thread pointer kept across steps)
+            asm volatile("" : "+v"(tz));
+            for (int zi = tz; zi < Z; zi += 256) dst[zi] = mom[zi];
         }
         if (tid == 0 && a.out_mean) {
             a.out_mean[((size_t)b * a.T + t) * 2] = mean0;
