@@ -193,7 +193,9 @@ def main():
         M = int(transition.rsplit('_', 1)[1])
         flops_step = 22.7 * N ** 3 + (8 * M + 12) * N ** 2
         tflops = live_steps * flops_step / (kern_ms_avg * 1e-3) / 1e12
-        traffic = recorded_hbm_traffic(args.workload, d_mom is not None)
+        # (the recorded counters belong to the workload's own size: no figure for --B / --T overrides)
+        full_size = (B == WORKLOADS[args.workload][3] and T == WORKLOADS[args.workload][2])
+        traffic = recorded_hbm_traffic(args.workload, d_mom is not None) if full_size else None
         out = {
             'metric': 'filter time-steps/sec', 'value': value, 'unit': 'filter-steps/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -329,8 +331,13 @@ def main_nd(args, rank, local_rank, world, N, T, B, mode, transition):
             'nll_allgather': ('rccl ncclAllGather' if comm.data == 'rccl' and world > 1 else
                               'single rank: device copy' if world == 1 else f'host fallback: {comm.rccl_error}'),
             'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': None, 'kernel': 'mfs::filternd_kernel',
+                         'frac': hbm_gbs / HBM_PEAK_GBS,
+                         'traffic': recorded_hbm_traffic(args.workload, d_mom is not None)
+                         if (B == WORKLOADS[args.workload][3] and T == WORKLOADS[args.workload][2]) else None,
+                         'kernel': 'mfs::filternd_kernel',
                          'avg_launch_ms': kern_ms_avg, 'algorithmic_bytes_per_launch': algo_bytes,
+                         'traffic_source': 'profiles/*/pmc.json (rocprofv3 --pmc, separate passes; the write counter includes '
+                                           'the kernel\'s scratch reload, see DESIGN.md section 3.3)',
                          'note': 'latency-bound small-matrix recursion (Jacobi rounds), not HBM-bound'},
         }
         if flops_step:
