@@ -355,3 +355,23 @@ def test_kernel_elementary_functions_against_libm():
     bad = run(2, np.array([0.0, -1.0, np.nan, np.inf]))
     assert not np.any(np.isfinite(bad))
     assert np.all(np.isnan(run(0, np.array([np.nan])))) and np.all(np.isnan(run(1, np.array([np.nan]))))
+
+
+@pytest.mark.parametrize('N', [14, 15, 16])
+def test_register_budget_builds_agree_bitwise(N):
+    """N = 14..16 exist in two builds of the same kernel (256 registers / 512 registers, csrc/filter1d_fast.hpp); the
+    plan picks the wide one when the batch puts at most one wave on a SIMD.  Eight measurement sequences repeated over a
+    batch large enough for the 256-register build must give exactly the numbers the small batch (wide build) gives."""
+    dt, T, ts, ic, drift, dispersion, logistic, pmf, _ = ss_models.benes_bernoulli(N)
+    _, c, _, mu, _ = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+    ys8, _ = synth.benes_bernoulli_batch(8, 40, dt, seed=11)
+    cm_s, me_s, nell_s = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys8)
+    reps = 4200 // (64 // (16 if N < 16 else 32)) + 8    # more single-wave workgroups than the 1024 SIMDs of an MI355X
+    ys = np.tile(ys8, (reps, 1))
+    cm_l, me_l, nell_l = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys)
+    assert np.isfinite(nell_s).any()
+    for r in (0, reps // 2, reps - 1):
+        sl = slice(8 * r, 8 * r + 8)
+        assert np.array_equal(nell_l[sl], nell_s, equal_nan=True)
+        assert np.array_equal(me_l[sl], me_s, equal_nan=True)
+        assert np.array_equal(cm_l[sl], cm_s, equal_nan=True)
