@@ -35,6 +35,9 @@ WORKLOADS = {
     'benes_bernoulli_N15_T1000_B4096_central_tme3': ('benes', 15, 1000, 4096, 'central', 'tme_3'),
     'benes_bernoulli_N7_T100_B4096_central_tme3': ('benes', 7, 100, 4096, 'central', 'tme_3'),
     'benes_bernoulli_N15_T1000_B4096_central_tme_normal3': ('benes', 15, 1000, 4096, 'central', 'tme_normal_3'),
+    # SURVEY section 8d asks for the raw (and scaled) representation of config 2 next to the central one, with divergence counts
+    'benes_bernoulli_N15_T1000_B4096_raw_tme3': ('benes', 15, 1000, 4096, 'raw', 'tme_3'),
+    'benes_bernoulli_N15_T1000_B4096_scaled_tme3': ('benes', 15, 1000, 4096, 'scaled', 'tme_3'),
     'well_poisson_N7_T1000_B131072_central_tme_normal2': ('well', 7, 1000, 131072, 'central', 'tme_normal_2'),
     # BASELINE config 5 (d = 2): per-GPU shard of the 512-replicate batch is set with --B (128 on 4 GPUs)
     'prey_predator_N6_T500_B512_central_tme2': ('prey', 6, 500, 512, 'central', 'tme_2'),
