@@ -213,9 +213,10 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     if (slot >= 3) p->lds_doubles += ((model->degree + 4) & ~3) * 10;  // fast path: + model table [ceil4(degree + 1)][kCoefRows]
     p->lds_bytes = p->fpb * p->lds_doubles * 8;
     {   // blocks of the fast path are single waves: with at most one per SIMD the wide-register variant costs nothing
-        hipDeviceProp_t prop;
-        p->single_wave_per_simd = (slot >= 3 && hipGetDeviceProperties(&prop, device) == hipSuccess &&
-                                   p->grid <= 4 * prop.multiProcessorCount);
+        int cus = 0;   // (hipDeviceGetAttribute: one integer, not the whole property structure, per plan)
+        p->single_wave_per_simd = (slot >= 3 &&
+                                   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+                                   p->grid <= 4 * cus);
     }
 
     const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * model->n_rows * (model->degree + 1);
