@@ -36,6 +36,7 @@ class Communicator:
         self._rdzv = None
         self._comm = None
         self.rccl_error = None
+        self._abandoned = False     # a RCCL initialisation that never returned is still sitting on a worker thread
         self.device = local_rank
 
     @classmethod
@@ -68,9 +69,11 @@ class Communicator:
                     self.data = 'host'
                 # every rank must take the same path
                 if any(self._allgather_obj(self.data != 'rccl')):
-                    if self._comm is not None:
+                    if self._comm is not None and not self._abandoned:
                         _lib.lib().mfs_comm_destroy(self._comm)
-                        self._comm = None
+                    self._comm = None
+                    if self.rccl_error is None:
+                        self.rccl_error = 'another rank could not join the RCCL communicator'
                     self.data = 'host'
         return self
 
@@ -83,15 +86,44 @@ class Communicator:
         self._td.all_gather_object(out, obj)
         return out
 
-    def _init_rccl(self):
+    def _init_rccl(self, timeout: float = None):
+        """ncclCommInitRank through the C ABI.  The call blocks until every rank has joined; a rank that died or never
+        got there would leave the others waiting forever, so it runs on a worker thread (ctypes releases the GIL) and is
+        given `timeout` seconds (MFS_RCCL_INIT_TIMEOUT, default 180).  On expiry this rank reports the failure and the
+        run continues on the host route; the worker is abandoned and `close()` then leaves through os._exit."""
+        import threading
         L = _lib.lib()
+        if timeout is None:
+            timeout = float(os.environ.get('MFS_RCCL_INIT_TIMEOUT', '180'))
         idbuf = (C.c_char * 128)()
+        err = None
         if self.rank == 0:
-            _lib.check(L.mfs_comm_unique_id(C.cast(idbuf, C.c_void_p)))
-        uid = self._allgather_obj(bytes(idbuf))[0]
+            try:
+                _lib.check(L.mfs_comm_unique_id(C.cast(idbuf, C.c_void_p)))
+            except _lib.MfsError as e:     # e.g. librccl missing: tell the others instead of leaving them in the gather
+                err = str(e)
+        uid, err0 = self._allgather_obj((bytes(idbuf), err))[0]
+        if err0 is not None:
+            raise _lib.MfsError(err0)
         idbuf = (C.c_char * 128).from_buffer_copy(uid)
         comm = C.c_void_p()
-        _lib.check(L.mfs_comm_init(C.byref(comm), C.cast(idbuf, C.c_void_p), self.world, self.rank, self.device))
+        result = {}
+
+        def work():
+            try:
+                _lib.check(L.mfs_comm_init(C.byref(comm), C.cast(idbuf, C.c_void_p), self.world, self.rank, self.device))
+                result['ok'] = True
+            except Exception as e:   # noqa: BLE001 -- reported below
+                result['err'] = str(e)
+
+        th = threading.Thread(target=work, name='mfs-rccl-init', daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            self._abandoned = True
+            raise _lib.MfsError(f'ncclCommInitRank did not return within {timeout:.0f} s on rank {self.rank}')
+        if 'err' in result:
+            raise _lib.MfsError(result['err'])
         self._comm = comm
 
     # -- control plane (host)
@@ -128,6 +160,13 @@ class Communicator:
         return np.concatenate(self._allgather_obj(local))
 
     def close(self):
+        if self._abandoned:
+            # the interpreter's shutdown would wait on (or tear down under) the stuck RCCL call: results are out, leave
+            import sys
+            self.barrier()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         if self._comm is not None:
             _lib.lib().mfs_comm_destroy(self._comm)
             self._comm = None
