@@ -96,6 +96,14 @@ __device__ __forceinline__ void fnma_bcast(double& acc, const double u, const do
     }
 }
 
+// two columns' updates from the same factor in one block: one hazard nop serves both
+template <int J0, int J1>
+__device__ __forceinline__ void fnma_bcast2(double& a0, double& a1, const double u, const double v) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %2, -%3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %2, -%3 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1) : "v"(v), "v"(u), "n"(J0), "n"(J1));
+}
+
 // acc = -u * (v of lane J of the group): the first term of a partial sum.  Where the broadcast is a separate move this
 // is a plain multiplication; v_mul_f64 has no DPP form, so 16-lane groups keep the multiply-add into a zero.
 template <int G, int J>
@@ -390,6 +398,38 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     double VrA[(G == 32) ? ((N < 16) ? N : 16) : 1], VrB[(G == 32) ? N : 1];
     double piv[N], sub[N], ipiv[N];  // group-uniform
     bool poisoned = false;
+#ifndef MFS_LEFT_LOOKING_8
+#define MFS_RL8 true
+#else
+#define MFS_RL8 false
+#endif
+    if constexpr (G == 16 || (G == 8 && MFS_RL8)) {
+        // right-looking order: as soon as column k is final every later column takes its term, two columns per asm
+        // block (one DPP hazard nop for both); each column is one accumulator, its updates a whole column apart
+        static_for<0, N>([&](auto Kc) {
+            constexpr int k = Kc;
+            const double s = g[k];
+            const double pj = bcast<G, k>(s);
+            piv[k] = pj;
+            sub[k] = bcast<G, k + 1>(s);
+            poisoned |= !(pj > 0.0);
+            const double y0 = __builtin_amdgcn_rcp(pj);
+            const double y1 = fma(fma(-pj, y0, 1.0), y0, y0);
+            const double delta = fma(-pj, y1, 1.0);
+            const double sy = s * y1;
+            ipiv[k] = fma(y1, delta, y1);
+            Ur[k] = s;
+            Vr[k] = fma(sy, delta, sy);
+            static_for<0, (N - 1 - k + 1) / 2>([&](auto Pc) {
+                constexpr int j0 = k + 1 + 2 * Pc;
+                if constexpr (G == 16 && j0 + 1 < N) fnma_bcast2<j0, j0 + 1>(g[j0], g[j0 + 1], Ur[k], Vr[k]);
+                else {
+                    if constexpr (j0 < N) fnma_bcast<G, j0>(g[j0], Ur[k], Vr[k]);
+                    if constexpr (G != 16 && j0 + 1 < N) fnma_bcast<G, j0 + 1>(g[j0 + 1], Ur[k], Vr[k]);
+                }
+            });
+        });
+    } else
     static_for<0, N>([&](auto Jc) {
         constexpr int j = Jc;
         double s = g[j], s2 = 0.0;   // two partial sums: the dot product is not one dependent chain
