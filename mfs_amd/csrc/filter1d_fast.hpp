@@ -104,6 +104,29 @@ __device__ __forceinline__ void fnma_bcast2(double& a0, double& a1, const double
         : "+v"(a0), "+v"(a1) : "v"(v), "v"(u), "n"(J0), "n"(J1));
 }
 
+template <int J0, int J1, int J2, int J3>
+__device__ __forceinline__ void fnma_bcast4(double& a0, double& a1, double& a2, double& a3, const double u, const double v) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %4, -%5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, -%5 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %4, -%5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %4, -%5 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(v), "v"(u), "n"(J0), "n"(J1), "n"(J2), "n"(J3));
+}
+
+template <int J0>
+__device__ __forceinline__ void fnma_bcast8(double* a, const double u, const double v) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %8, -%9 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %8, -%9 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %8, -%9 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %8, -%9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %8, -%9 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %5, %8, -%9 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %6, %8, -%9 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %7, %8, -%9 row_newbcast:%17 row_mask:0xf bank_mask:0xf"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "v"(v), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3), "n"(J0 + 4), "n"(J0 + 5), "n"(J0 + 6), "n"(J0 + 7));
+}
+
 // acc = -u * (v of lane J of the group): the first term of a partial sum.  Where the broadcast is a separate move this
 // is a plain multiplication; v_mul_f64 has no DPP form, so 16-lane groups keep the multiply-add into a zero.
 template <int G, int J>
@@ -398,14 +421,12 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     double VrA[(G == 32) ? ((N < 16) ? N : 16) : 1], VrB[(G == 32) ? N : 1];
     double piv[N], sub[N], ipiv[N];  // group-uniform
     bool poisoned = false;
-#ifndef MFS_LEFT_LOOKING_8
-#define MFS_RL8 true
-#else
-#define MFS_RL8 false
-#endif
-    if constexpr (G == 16 || (G == 8 && MFS_RL8)) {
-        // right-looking order: as soon as column k is final every later column takes its term, two columns per asm
-        // block (one DPP hazard nop for both); each column is one accumulator, its updates a whole column apart
+    if constexpr (G == 16 || G == 8) {
+        // right-looking order: as soon as column k is final every later column takes its term.  Each column is one
+        // accumulator (its updates arrive a whole column apart, so no dependent-issue stall and no partial sums to add),
+        // and for 16-lane groups the terms of one factor go out in asm blocks of 8 / 4 / 2 fused v_fmac_f64_dpp that
+        // share a single DPP hazard nop (left-looking with two partial sums per column: 8.25 ms on config 2; this
+        // order in pairs 7.79, fours 7.69, eights 7.62; the next pivot's column on its own in front: no better)
         static_for<0, N>([&](auto Kc) {
             constexpr int k = Kc;
             const double s = g[k];
@@ -413,6 +434,8 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             piv[k] = pj;
             sub[k] = bcast<G, k + 1>(s);
             poisoned |= !(pj > 0.0);
+            // 1 / pivot: hardware v_rcp_f64 seed + two Newton-Raphson steps -> ~1e-16; the second step is folded into
+            // the consumers (y1 (1 + delta) with delta = 1 - pivot y1) so that s * y1 and delta form side by side
             const double y0 = __builtin_amdgcn_rcp(pj);
             const double y1 = fma(fma(-pj, y0, 1.0), y0, y0);
             const double delta = fma(-pj, y1, 1.0);
@@ -420,14 +443,22 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             ipiv[k] = fma(y1, delta, y1);
             Ur[k] = s;
             Vr[k] = fma(sy, delta, sy);
-            static_for<0, (N - 1 - k + 1) / 2>([&](auto Pc) {
-                constexpr int j0 = k + 1 + 2 * Pc;
-                if constexpr (G == 16 && j0 + 1 < N) fnma_bcast2<j0, j0 + 1>(g[j0], g[j0 + 1], Ur[k], Vr[k]);
-                else {
-                    if constexpr (j0 < N) fnma_bcast<G, j0>(g[j0], Ur[k], Vr[k]);
-                    if constexpr (G != 16 && j0 + 1 < N) fnma_bcast<G, j0 + 1>(g[j0 + 1], Ur[k], Vr[k]);
-                }
-            });
+            if constexpr (G == 16) {
+                constexpr int n8 = (N - (k + 1)) / 8;
+                static_for<0, n8>([&](auto Pc) { fnma_bcast8<k + 1 + 8 * Pc>(&g[k + 1 + 8 * Pc], Ur[k], Vr[k]); });
+                constexpr int jq = k + 1 + 8 * n8;
+                static_for<0, (N - jq + 3) / 4>([&](auto Pc) {
+                    constexpr int j0 = jq + 4 * Pc;
+                    if constexpr (j0 + 3 < N) fnma_bcast4<j0, j0 + 1, j0 + 2, j0 + 3>(g[j0], g[j0 + 1], g[j0 + 2], g[j0 + 3], Ur[k], Vr[k]);
+                    else {
+                        if constexpr (j0 + 1 < N) fnma_bcast2<j0, j0 + 1>(g[j0], g[j0 + 1], Ur[k], Vr[k]);
+                        else if constexpr (j0 < N) fnma_bcast<G, j0>(g[j0], Ur[k], Vr[k]);
+                        if constexpr (j0 + 2 < N) fnma_bcast<G, j0 + 2>(g[j0 + 2], Ur[k], Vr[k]);
+                    }
+                });
+            } else {
+                static_for<k + 1, N>([&](auto Jc) { fnma_bcast<G, Jc>(g[Jc], Ur[k], Vr[k]); });
+            }
         });
     } else
     static_for<0, N>([&](auto Jc) {
