@@ -410,7 +410,8 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     __builtin_amdgcn_sched_barrier(0);
 
     F1_STAMP(0);
-    // -- Cholesky, row per lane, left-looking by column (quadtures.py:127), kept in its square-root-free form: only the
+    // -- Cholesky, row per lane (quadtures.py:127; right-looking for 8- / 16-lane groups, left-looking by column for 32),
+    //    kept in its square-root-free form: only the
     //    pivots d_j = L_jj^2 and the sub-diagonal enter the Jacobi matrix below, and L_ik L_jk = u_ik u_jk / d_k with the
     //    unnormalised columns u, so no square root is ever taken.  u_jk / d_k reaches the other lanes by DPP.
     double Ur[N], Vr[N];             // u_lk and u_lk / d_k of this lane's row
