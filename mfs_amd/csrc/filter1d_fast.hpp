@@ -410,16 +410,15 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     __builtin_amdgcn_sched_barrier(0);
 
     F1_STAMP(0);
-    // -- Cholesky, row per lane (quadtures.py:127; right-looking for 8- / 16-lane groups, left-looking by column for 32),
+    // -- Cholesky, row per lane (quadtures.py:127; right-looking for 8- / 16- / 32-lane groups, left-looking by column for 64),
     //    kept in its square-root-free form: only the
     //    pivots d_j = L_jj^2 and the sub-diagonal enter the Jacobi matrix below, and L_ik L_jk = u_ik u_jk / d_k with the
     //    unnormalised columns u, so no square root is ever taken.  u_jk / d_k reaches the other lanes by DPP.
     double Ur[N], Vr[N];             // u_lk and u_lk / d_k of this lane's row
     // G = 32: a group spans two DPP rows, and row_newbcast only reaches inside a row.  gfx950's v_permlane16_swap on
     // (v, copy of v) leaves the even row's data in both rows of one register and the odd row's in both rows of the
-    // other: with those two copies of every u_lk / d_k the broadcast is again the DPP operand of the multiply-add
+    // other: with those two copies of u_lk / d_k the broadcast is again the DPP operand of the multiply-add
     // (lane j < 16 from the first copy, else from the second), instead of two ds_swizzle round trips per term.
-    double VrA[(G == 32) ? ((N < 16) ? N : 16) : 1], VrB[(G == 32) ? N : 1];
     double piv[N], sub[N], ipiv[N];  // group-uniform
     bool poisoned = false;
     if constexpr (G == 16 || G == 8) {
@@ -461,21 +460,49 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                 static_for<k + 1, N>([&](auto Jc) { fnma_bcast<G, Jc>(g[Jc], Ur[k], Vr[k]); });
             }
         });
-    } else
+    } else if constexpr (G == 32) {
+        // the same order for two-row groups: the factor is duplicated over the rows once (row_dup) and used at once for
+        // every later column -- lanes below 16 from the even-row copy, the others from the odd-row copy -- so no copies
+        // of earlier factors are kept
+        static_for<0, N>([&](auto Kc) {
+            constexpr int k = Kc;
+            const double s = g[k];
+            const double pj = bcast<G, k>(s);
+            piv[k] = pj;
+            sub[k] = bcast<G, k + 1>(s);
+            poisoned |= !(pj > 0.0);
+            const double y0 = __builtin_amdgcn_rcp(pj);
+            const double y1 = fma(fma(-pj, y0, 1.0), y0, y0);
+            const double delta = fma(-pj, y1, 1.0);
+            const double sy = s * y1;
+            ipiv[k] = fma(y1, delta, y1);
+            const double vk = fma(sy, delta, sy);
+            if constexpr (k + 1 < N) {
+                double va, vb;
+                row_dup(vk, va, vb);
+                constexpr int lo_end = (N < 16) ? N : 16;                   // columns k + 1 .. lo_end - 1 read the even-row copy
+                if constexpr (k + 1 < lo_end) {
+                    constexpr int n8 = (lo_end - (k + 1)) / 8;
+                    static_for<0, n8>([&](auto Pc) { fnma_bcast8<k + 1 + 8 * Pc>(&g[k + 1 + 8 * Pc], s, va); });
+                    static_for<k + 1 + 8 * n8, lo_end>([&](auto Jc) { fnma_bcast<16, Jc>(g[Jc], s, va); });
+                }
+                constexpr int hi0 = (k + 1 > 16) ? k + 1 : 16;              // columns >= 16: lane j - 16 of the odd-row copy
+                if constexpr (hi0 < N) {
+                    constexpr int n8 = (N - hi0) / 8;
+                    static_for<0, n8>([&](auto Pc) { fnma_bcast8<hi0 - 16 + 8 * Pc>(&g[hi0 + 8 * Pc], s, vb); });
+                    static_for<hi0 + 8 * n8, N>([&](auto Jc) { fnma_bcast<16, Jc - 16>(g[Jc], s, vb); });
+                }
+            }
+        });
+    } else   // whole-wave groups (N = 32, or on request): left-looking by column, the dot product in two partial sums
     static_for<0, N>([&](auto Jc) {
         constexpr int j = Jc;
         double s = g[j], s2 = 0.0;   // two partial sums: the dot product is not one dependent chain
         static_for<0, j>([&](auto Kc) {
             constexpr int k = Kc;
             constexpr int k0 = ((j - 1) % 2 == 1) ? 0 : 1;   // first term of s2
-            if constexpr (G != 32 && k == k0) {
+            if constexpr (k == k0) {
                 nmul_bcast<G, j>(s2, Ur[k], Vr[k]);
-            } else if constexpr (G == 32) {
-                if constexpr (j < 16) {
-                    if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<16, j>(s, Ur[k], VrA[k]); else fnma_bcast<16, j>(s2, Ur[k], VrA[k]);
-                } else {
-                    if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<16, j - 16>(s, Ur[k], VrB[k]); else fnma_bcast<16, j - 16>(s2, Ur[k], VrB[k]);
-                }
             } else if constexpr ((j - 1 - k) % 2 == 0) fnma_bcast<G, j>(s, Ur[k], Vr[k]);   // k = j - 1 (the late one) lands here
             else fnma_bcast<G, j>(s2, Ur[k], Vr[k]);
         });
@@ -493,12 +520,6 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         ipiv[j] = fma(y1, delta, y1);
         Ur[j] = s;
         Vr[j] = fma(sy, delta, sy);
-        if constexpr (G == 32) {
-            double va, vb;
-            row_dup(Vr[j], va, vb);
-            if constexpr (j < 16) VrA[j] = va;
-            VrB[j] = vb;
-        }
     });
 
     F1_STAMP(1);
