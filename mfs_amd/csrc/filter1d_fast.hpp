@@ -127,6 +127,16 @@ __device__ __forceinline__ void fnma_bcast8(double* a, const double u, const dou
         : "v"(v), "v"(u), "n"(J0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3), "n"(J0 + 4), "n"(J0 + 5), "n"(J0 + 6), "n"(J0 + 7));
 }
 
+// acc[j] -= u * (v of lane j - OFF of this lane's DPP row) for the columns j = J0 .. J1 - 1: blocks of eight, then singles
+template <int J0, int J1, int OFF>
+__device__ __forceinline__ void fnma_bcast_range(double* acc, const double u, const double v) {
+    if constexpr (J0 < J1) {
+        constexpr int n8 = (J1 - J0) / 8;
+        static_for<0, n8>([&](auto Pc) { fnma_bcast8<J0 - OFF + 8 * Pc>(acc + J0 + 8 * Pc, u, v); });
+        static_for<J0 + 8 * n8, J1>([&](auto Jc) { fnma_bcast<16, Jc - OFF>(acc[Jc], u, v); });
+    }
+}
+
 // acc = -u * (v of lane J of the group): the first term of a partial sum.  Where the broadcast is a separate move this
 // is a plain multiplication; v_mul_f64 has no DPP form, so 16-lane groups keep the multiply-add into a zero.
 template <int G, int J>

@@ -234,14 +234,13 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             double D0[S0], D1[(S > 16) ? S : 1];      // column k of L: DPP row 0 / DPP row 1 of it in all four rows
             static_for<0, S>([&](auto Jc) { Lr[Jc] = A[li * LD + Jc]; xc[Jc] = K[hm * NP * LD + Jc * LD + hj]; });
             bool bad = false;
+            // right-looking: a final column is subtracted from every later column at once (blocks of eight fused DPP
+            // multiply-adds behind one hazard nop, independent accumulators) -- each column still receives its terms in
+            // the order k = 0, 1, ..., so the numbers are those of the column-by-column form
+            constexpr int loE = (S < 16) ? S : 16;
             static_for<0, S>([&](auto Jc) {
                 constexpr int j = Jc;
-                double s = Lr[j], xa = xc[j];
-                static_for<0, j>([&](auto Kc) {
-                    constexpr int k = Kc;
-                    if constexpr (j < 16) { fnma_bcast<16, j>(s, Lr[k], D0[k]); fnma_bcast<16, j>(xa, xc[k], D0[k]); }
-                    else { fnma_bcast<16, j - 16>(s, Lr[k], D1[k]); fnma_bcast<16, j - 16>(xa, xc[k], D1[k]); }
-                });
+                const double s = Lr[j], xa = xc[j];
                 const double pj = bcast<64, j>(s);
                 bad |= !(pj > 0.0);
                 const double rinv = rsq_nr(pj);
@@ -253,6 +252,15 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                     row_dup(Lr[j], ev, od);
                     if constexpr (j < S0) { half_dup(ev, lo, up); D0[j] = lo; }
                     if constexpr (S > 16) { half_dup(od, lo, up); D1[j] = lo; }
+                    if constexpr (j + 1 < loE) {
+                        fnma_bcast_range<j + 1, loE, 0>(Lr, Lr[j], D0[j]);
+                        fnma_bcast_range<j + 1, loE, 0>(xc, xc[j], D0[j]);
+                    }
+                    if constexpr (S > 16) {
+                        constexpr int hi0 = (j + 1 > 16) ? j + 1 : 16;
+                        fnma_bcast_range<hi0, S, 16>(Lr, Lr[j], D1[j]);
+                        fnma_bcast_range<hi0, S, 16>(xc, xc[j], D1[j]);
+                    }
                 }
             });
             if (tid == 0 && bad) flags[0] = 1.0;
@@ -264,13 +272,12 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             static_for<0, S>([&](auto Jc) { yr[Jc] = K[hm * NP * LD + hj * LD + Jc]; });
             static_for<0, S>([&](auto Ic) {
                 constexpr int i = Ic;
-                double acc = yr[i];
-                static_for<0, i>([&](auto Kc) {
-                    constexpr int k = Kc;
-                    if constexpr (i < 16) fnma_bcast<16, i>(acc, yr[k], D0[k]);
-                    else fnma_bcast<16, i - 16>(acc, yr[k], D1[k]);
-                });
-                yr[i] = acc * rinv_lds[i];
+                yr[i] = yr[i] * rinv_lds[i];
+                if constexpr (i + 1 < loE) fnma_bcast_range<i + 1, loE, 0>(yr, yr[i], D0[i]);
+                if constexpr (S > 16 && i + 1 < S) {
+                    constexpr int hi0 = (i + 1 > 16) ? i + 1 : 16;
+                    fnma_bcast_range<hi0, S, 16>(yr, yr[i], D1[i]);
+                }
             });
             wave_sync();
             static_for<0, S>([&](auto Jc) { if (tid < 2 * S) K[hm * NP * LD + hj * LD + Jc] = yr[Jc]; });
