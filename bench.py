@@ -386,7 +386,12 @@ def recorded_hbm_traffic(workload, moments_streamed):
     process; they are collected with rocprofv3 --pmc in separate passes and committed under profiles/)."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc.json'))):
+    import re
+
+    def natural(path):   # r01_v9 before r01_v10
+        return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', path)]
+
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc.json')), key=natural):
         try:
             with open(path) as f:
                 rec = json.load(f)
