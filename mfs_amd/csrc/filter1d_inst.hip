@@ -1,6 +1,7 @@
 // filter1d_inst.hip -- instantiates the 1-D kernels for quadrature orders MFS_NLO..MFS_NHI (one translation unit per
 // range so that `make -j` compiles them in parallel) and registers their launchers.
 #include "filter1d_fast.hpp"
+#include "launch_util.hpp"
 
 #ifndef MFS_NLO
 #error "compile with -DMFS_NLO=.. -DMFS_NHI=.."
@@ -25,13 +26,7 @@ constexpr int waves_per_block() {
 template <int N, int G>
 hipError_t launch_filter(const Filter1dArgs& a, int grid, int lds, hipStream_t s) {
     constexpr int WPB = waves_per_block<N, G>();
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter1d_kernel<N, G, WPB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&filter1d_kernel<N, G, WPB>>(); e != hipSuccess) return e;
     hipLaunchKernelGGL((filter1d_kernel<N, G, WPB>), dim3(grid), dim3(WPB * 64), lds, s, a);
     return hipGetLastError();
 }
@@ -39,13 +34,7 @@ hipError_t launch_filter(const Filter1dArgs& a, int grid, int lds, hipStream_t s
 template <int N, int G>
 hipError_t launch_quad(const Quad1dArgs& a, int grid, int lds, hipStream_t s) {
     constexpr int WPB = waves_per_block<N, G>();
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&quadrature1d_kernel<N, G, WPB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&quadrature1d_kernel<N, G, WPB>>(); e != hipSuccess) return e;
     hipLaunchKernelGGL((quadrature1d_kernel<N, G, WPB>), dim3(grid), dim3(WPB * 64), lds, s, a);
     return hipGetLastError();
 }
@@ -63,13 +52,7 @@ void reg(int gi) {
 // ---- fast (register-resident) path: single-wave workgroups, LDS = filters per wave x (fixed + model table)
 template <int N, int G, int OCC>
 hipError_t launch_filter_fast(const Filter1dArgs& a, int grid, int lds_doubles, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter1d_fast_kernel<N, G, 1, OCC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&filter1d_fast_kernel<N, G, 1, OCC>>(); e != hipSuccess) return e;
     hipLaunchKernelGGL((filter1d_fast_kernel<N, G, 1, OCC>), dim3(grid), dim3(64), (64 / G) * lds_doubles * 8, s, a,
                        lds_doubles);
     return hipGetLastError();

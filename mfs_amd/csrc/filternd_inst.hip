@@ -1,6 +1,7 @@
 // filternd_inst.hip -- instantiates the d = 2 N-D kernels for quadrature orders 2..7, both transition families
 // (TK = 0 operator table, TK = 1 Normal closure), and registers their launchers.
 #include "filternd_kernel.hpp"
+#include "launch_util.hpp"
 
 namespace mfs {
 
@@ -11,13 +12,7 @@ NdEntry g_nd_table[8];
 template <int N, int TK>
 hipError_t launch_nd(const FilterNdArgs& a, int grid, hipStream_t s) {
     constexpr int lds = NdTile<N>::kDoubles * 8;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, TK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds<&filternd_kernel<N, TK>>(); e != hipSuccess) return e;
     hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }

@@ -14,6 +14,9 @@ import numpy as np
 from mfs_amd import _lib
 
 
+EXIT_RCCL_FAILED = 3   # exit status of a multi-rank run whose NLL gather did not go through RCCL
+
+
 def shard_bounds(B: int, world: int, rank: int):
     """Contiguous block split of the replicate axis: rank g owns [lo, hi)."""
     base, rem = divmod(B, world)
@@ -90,7 +93,8 @@ class Communicator:
         """ncclCommInitRank through the C ABI.  The call blocks until every rank has joined; a rank that died or never
         got there would leave the others waiting forever, so it runs on a worker thread (ctypes releases the GIL) and is
         given `timeout` seconds (MFS_RCCL_INIT_TIMEOUT, default 180).  On expiry this rank reports the failure and the
-        run continues on the host route; the worker is abandoned and `close()` then leaves through os._exit."""
+        run continues on the host route; the worker is abandoned and `close()` then leaves through os._exit with
+        `EXIT_RCCL_FAILED` (an abandoned collective initialisation is never a successful run)."""
         import threading
         L = _lib.lib()
         if timeout is None:
@@ -125,6 +129,11 @@ class Communicator:
         if 'err' in result:
             raise _lib.MfsError(result['err'])
         self._comm = comm
+
+    @property
+    def degraded(self) -> bool:
+        """True when a multi-rank run asked for the RCCL data path and is not on it (see `rccl_error`)."""
+        return self.world > 1 and self.rccl_error is not None
 
     # -- control plane (host)
     def barrier(self):
@@ -166,7 +175,7 @@ class Communicator:
             self.barrier()
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(EXIT_RCCL_FAILED)
         if self._comm is not None:
             _lib.lib().mfs_comm_destroy(self._comm)
             self._comm = None
