@@ -106,6 +106,20 @@ int mfs_memset(void* dst, int value, uint64_t bytes, void* stream);
 int mfs_stream_create(void** stream);
 int mfs_stream_destroy(void* stream);
 int mfs_stream_synchronize(void* stream);
+/*
+ * The library's staging pool (SURVEY.md section 8b "Ownership": the caller owns what it passes; the library stages
+ * through its own device buffers and pinned pool, reused across calls).  The host-pointer entry points below borrow
+ * their device buffers, streams and events from per-device caches, so a steady-state call makes no hipMalloc / hipFree.
+ * mfs_host_alloc hands out page-locked host memory from the same pool: results written into it (e.g. out_moments)
+ * travel at the PCIe rate instead of the pageable-copy rate, and a block given back with mfs_host_free is reused by
+ * the next request of similar size.  mfs_pool_trim returns every unused block (device, pinned, streams) to the driver;
+ * mfs_pool_stats reports bytes held and the number of driver allocations made so far (NULL = not wanted).
+ */
+int mfs_host_alloc(void** ptr, uint64_t bytes, int device);
+int mfs_host_free(void* ptr);
+int mfs_pool_trim(int device);
+int mfs_pool_stats(int device, uint64_t* device_bytes, uint64_t* pinned_bytes, uint64_t* device_allocs,
+                   uint64_t* pinned_allocs);
 /* HIP-event timing on `stream` (bench.py's live per-launch kernel time) */
 int mfs_event_create(void** event);
 int mfs_event_destroy(void* event);
@@ -127,8 +141,12 @@ int mfs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on
  *   stable      0 = Cholesky; 1 = LDL^T completion (mfs/utils.py:495-538)
  *   out_moments [B][T][2N]   out_means [B][T] (NULL in raw mode)   out_scales [B][T] (scaled mode, else NULL)
  *   out_nell    [B]          out_first_nan [B]: first step whose outputs are non-finite, -1 if none (may be NULL)
- *   device      HIP device ordinal; stream: hipStream_t or NULL (default stream).  Returns after the results are
- *               in the host buffers.
+ *   device      HIP device ordinal; stream: hipStream_t or NULL (a stream of the library's).  Returns after the
+ *               results are in the host buffers.
+ * When out_moments is requested and large, the run is split into T-chunks (carry state in HBM, bit-identical to one
+ * launch) and each chunk's slice of the moments is copied out while the next chunk computes (MFS_HOST_CHUNKS=n
+ * overrides the chunk count, 1 = no pipelining).  Per-replicate parameters theta arrive as
+ * batched model tables (model->coef_batched / lik_batched), not as a separate argument.
  */
 int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B,
                   const double* m0, int m0_batched, const double* mean0, const double* scale0,
@@ -258,7 +276,7 @@ int mfs_plan_nd_geometry(const mfs_plan_nd* plan, int* threads_per_filter, int* 
  * dardel/run_benes_bernoulli_mf.sh:26-31); replicates share nothing, so the data path needs no collective and the
  * only exchange is one ncclAllGather of the per-replicate negative log-likelihoods after the kernel
  * (SURVEY.md section 8e).  Rank 0 creates an id, the host side distributes its 128 bytes by any means
- * (mfs_amd/dist.py uses torch.distributed's store), every rank calls mfs_comm_init.
+ * (mfs_amd/dist.py sends it over its TCP control plane, mfs_amd/rdzv.py), every rank calls mfs_comm_init.
  */
 typedef struct mfs_rccl_id { char bytes[128]; } mfs_rccl_id; /* = ncclUniqueId */
 int mfs_comm_unique_id(mfs_rccl_id* id);

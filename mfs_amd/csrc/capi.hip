@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "filternd_kernel.hpp"
+#include "pool.hpp"
 
 namespace mfs {
 KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
@@ -104,7 +105,7 @@ struct mfs_plan_1d {
     double* c_nell = nullptr;
     int32_t* c_first_nan = nullptr;
     double* c_lam = nullptr;
-    hipStream_t own_stream = nullptr;
+    hipStream_t own_stream = nullptr;   // created on first use (run() without a caller stream, graph capture)
     // cached graph for the last set of run() pointers
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -176,15 +177,23 @@ int mfs_event_elapsed_ms(void* start, void* stop, float* ms) {
 // ---------------------------------------------------------------------------------------------------------------
 // plans
 // ---------------------------------------------------------------------------------------------------------------
-int mfs_plan_1d_destroy(mfs_plan_1d* p) {
-    if (!p) return MFS_OK;
+// `quiesced`: the caller has already synchronised every stream the plan's buffers were used on
+static void destroy_plan_1d(mfs_plan_1d* p, bool quiesced) {
     hipSetDevice(p->device);
+    if (!quiesced) hipDeviceSynchronize();   // what hipFree did implicitly: pool blocks must be idle when they go back
     if (p->exec) hipGraphExecDestroy(p->exec);
     if (p->graph) hipGraphDestroy(p->graph);
-    hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->c_mom); hipFree(p->c_mean); hipFree(p->c_scale);
-    hipFree(p->c_nell); hipFree(p->c_first_nan); hipFree(p->c_lam);
+    // model tables and carry state come from the device pool (pool.hpp): a plan per call costs no hipMalloc / hipFree
+    mfs::BlockPool<false>& pool = mfs::device_state(p->device).device;
+    for (void* b : {(void*)p->d_coef, (void*)p->d_lik, (void*)p->c_mom, (void*)p->c_mean, (void*)p->c_scale,
+                    (void*)p->c_nell, (void*)p->c_first_nan, (void*)p->c_lam})
+        pool.release(b);
     if (p->own_stream) hipStreamDestroy(p->own_stream);
     delete p;
+}
+
+int mfs_plan_1d_destroy(mfs_plan_1d* p) {
+    if (p) destroy_plan_1d(p, false);
     return MFS_OK;
 }
 
@@ -222,7 +231,8 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * model->n_rows * (model->degree + 1);
     const size_t nlik = (size_t)(model->lik_batched ? B : 1) * model->n_lik;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
+    mfs::BlockPool<false>& pool = mfs::device_state(device).device;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = pool.acquire(d, bytes); };
     alloc((void**)&p->d_coef, ncoef * 8);
     alloc((void**)&p->d_lik, nlik * 8);
     alloc((void**)&p->c_mom, (size_t)B * 2 * N * 8);
@@ -233,9 +243,8 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     if (p->chunk < T && slot >= 3) alloc((void**)&p->c_lam, (size_t)B * p->G * 8);
     if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, ncoef * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, nlik * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
-        mfs_plan_1d_destroy(p);
+        destroy_plan_1d(p, true);
         return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "plan setup failed: %s", hipGetErrorString(e));
     }
     p->model.coef = p->d_coef;
@@ -279,17 +288,10 @@ static int enqueue_chunks(mfs_plan_1d* p, const mfs::Filter1dArgs& base, hipStre
     return MFS_OK;
 }
 
-int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const double* d_mean0,
-                    const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
-                    double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream) {
-    if (!p) return fail(MFS_EINVAL, "plan is NULL");
-    if (!d_m0 || !d_out_nell || (p->T > 0 && !d_ys)) return fail(MFS_EINVAL, "m0 / ys / out_nell must not be NULL");
-    if (p->mode != MFS_MODE_RAW && !d_mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
-    if (p->mode == MFS_MODE_SCALED && !d_scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
-    if (p->B == 0) return MFS_OK;
-    HIP_TRY(hipSetDevice(p->device));
-    hipStream_t s = stream ? (hipStream_t)stream : p->own_stream;
-
+static mfs::Filter1dArgs plan_args(const mfs_plan_1d* p, const double* d_m0, int m0_batched, const double* d_mean0,
+                                    const double* d_scale0, const double* d_ys, double* d_out_moments,
+                                    double* d_out_means, double* d_out_scales, double* d_out_nell,
+                                    int32_t* d_out_first_nan) {
     mfs::Filter1dArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = p->mode; a.T = p->T; a.B = p->B; a.stable = p->stable;
@@ -304,8 +306,24 @@ int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const do
     a.out_mom = d_out_moments; a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
     a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
     a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
+    return a;
+}
 
+int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const double* d_mean0,
+                    const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
+                    double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream) {
+    if (!p) return fail(MFS_EINVAL, "plan is NULL");
+    if (!d_m0 || !d_out_nell || (p->T > 0 && !d_ys)) return fail(MFS_EINVAL, "m0 / ys / out_nell must not be NULL");
+    if (p->mode != MFS_MODE_RAW && !d_mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
+    if (p->mode == MFS_MODE_SCALED && !d_scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    if (p->B == 0) return MFS_OK;
+    HIP_TRY(hipSetDevice(p->device));
     const int nchunks = (p->T + p->chunk - 1) / (p->chunk > 0 ? p->chunk : 1);
+    if (!p->own_stream && (!stream || nchunks > 1)) HIP_TRY(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
+    hipStream_t s = stream ? (hipStream_t)stream : p->own_stream;
+
+    const mfs::Filter1dArgs a = plan_args(p, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_out_moments, d_out_means,
+                                          d_out_scales, d_out_nell, d_out_first_nan);
     if (nchunks <= 1) return enqueue_chunks(p, a, s);  // one launch: a graph adds only replay overhead
 
     // several chunk launches: capture them once into a hipGraph keyed on the buffer set, then replay
@@ -331,6 +349,17 @@ int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const do
 // ---------------------------------------------------------------------------------------------------------------
 // host-pointer convenience path
 // ---------------------------------------------------------------------------------------------------------------
+// How many T-chunks the host entry splits a run into when the moments are streamed out: the kernel of chunk k + 1 runs
+// while chunk k's slice of out_moments travels to the host (2-D copy: B rows of chunk x 2N doubles).  MFS_HOST_CHUNKS
+// overrides (1 = one launch, copies afterwards).
+static int host_chunks(size_t moment_bytes, int T) {
+    int n = (int)(moment_bytes / ((size_t)64 << 20));
+    if (const char* e = getenv("MFS_HOST_CHUNKS")) n = atoi(e);
+    if (n > 16) n = 16;
+    if (n > T) n = T;
+    return n < 1 ? 1 : n;
+}
+
 int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B, const double* m0, int m0_batched,
                   const double* mean0, const double* scale0, const double* ys, int stable, double* out_moments,
                   double* out_means, double* out_scales, double* out_nell, int32_t* out_first_nan, int device,
@@ -338,50 +367,78 @@ int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B, cons
     if (!m0 || !out_nell || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "m0 / ys / out_nell must not be NULL");
     if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
     if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
-    mfs_plan_1d* p = nullptr;
-    if (int rc = mfs_plan_1d_create(&p, model, mode, N, T, B, stable, 0, device)) return rc;
-    if (B == 0) { mfs_plan_1d_destroy(p); return MFS_OK; }
-    hipStream_t s = stream ? (hipStream_t)stream : p->own_stream;
     const size_t M2 = 2 * (size_t)N, nb = m0_batched ? B : 1;
+    const size_t mom_bytes = out_moments ? (size_t)B * T * M2 * 8 : 0;
+    const int nchunks = (B > 0 && T > 0) ? host_chunks(mom_bytes, T) : 1;
+    const int chunk = (nchunks > 1) ? (T + nchunks - 1) / nchunks : 0;
+    mfs_plan_1d* p = nullptr;
+    if (int rc = mfs_plan_1d_create(&p, model, mode, N, T, B, stable, chunk, device)) return rc;
+    struct PlanGuard { mfs_plan_1d* p; ~PlanGuard() { destroy_plan_1d(p, true); } } guard{p};  // (every exit below is quiesced)
+    if (B == 0) return MFS_OK;
+
+    // device staging from the library's pool, streams / events from its context cache: no hipMalloc, hipFree,
+    // hipStreamCreate or hipEventCreate on a steady-state call (SURVEY.md section 8b "Ownership")
+    mfs::Lease lease(device);
+    mfs::CallContext* cx = nullptr;
     double *d_m0 = nullptr, *d_mean0 = nullptr, *d_scale0 = nullptr, *d_ys = nullptr, *d_mom = nullptr,
            *d_means = nullptr, *d_scales = nullptr, *d_nell = nullptr;
     int32_t* d_fn = nullptr;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
+    hipError_t e = lease.context(&cx);
+    auto alloc = [&](auto** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block(d, bytes); };
+    alloc(&d_m0, nb * M2 * 8);
+    alloc(&d_mean0, nb * 8);
+    alloc(&d_scale0, nb * 8);
+    alloc(&d_ys, (size_t)B * T * 8);
+    if (out_moments) alloc(&d_mom, mom_bytes);
+    if (out_means && mode != MFS_MODE_RAW) alloc(&d_means, (size_t)B * T * 8);
+    if (out_scales && mode == MFS_MODE_SCALED) alloc(&d_scales, (size_t)B * T * 8);
+    alloc(&d_nell, (size_t)B * 8);
+    alloc(&d_fn, (size_t)B * 4);
+    if (e != hipSuccess)
+        return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_1d staging: %s", hipGetErrorString(e));
+    hipStream_t s = stream ? (hipStream_t)stream : cx->compute;
     auto h2d = [&](void* d, const void* h, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
     };
-    auto d2h = [&](void* h, const void* d, size_t bytes) {
-        if (e == hipSuccess && h && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
-    };
-    alloc((void**)&d_m0, nb * M2 * 8);
-    alloc((void**)&d_mean0, nb * 8);
-    alloc((void**)&d_scale0, nb * 8);
-    alloc((void**)&d_ys, (size_t)B * T * 8);
-    if (out_moments) alloc((void**)&d_mom, (size_t)B * T * M2 * 8);
-    if (out_means && mode != MFS_MODE_RAW) alloc((void**)&d_means, (size_t)B * T * 8);
-    if (out_scales && mode == MFS_MODE_SCALED) alloc((void**)&d_scales, (size_t)B * T * 8);
-    alloc((void**)&d_nell, (size_t)B * 8);
-    alloc((void**)&d_fn, (size_t)B * 4);
     h2d(d_m0, m0, nb * M2 * 8);
     if (mean0) h2d(d_mean0, mean0, nb * 8);
     if (scale0) h2d(d_scale0, scale0, nb * 8);
     h2d(d_ys, ys, (size_t)B * T * 8);
+
     int rc = MFS_OK;
-    if (e == hipSuccess)
-        rc = mfs_plan_1d_run(p, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn, s);
-    if (rc == MFS_OK) {
-        d2h(out_moments, d_mom, (size_t)B * T * M2 * 8);
-        d2h(out_means, d_means, d_means ? (size_t)B * T * 8 : 0);
-        d2h(out_scales, d_scales, d_scales ? (size_t)B * T * 8 : 0);
-        d2h(out_nell, d_nell, (size_t)B * 8);
-        d2h(out_first_nan, d_fn, (size_t)B * 4);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) {
+        mfs::Filter1dArgs a = plan_args(p, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn);
+        if (nchunks <= 1) {
+            rc = enqueue_chunks(p, a, s);
+            if (rc == MFS_OK && out_moments && T > 0) e = hipMemcpyAsync(out_moments, d_mom, mom_bytes, hipMemcpyDeviceToHost, s);
+        } else {
+            // chunk launches on `s`; after each one an event releases that chunk's slice of the moments to the copy
+            // stream -- same chunking, same carry and therefore the same bits as the plan's graph of chunk launches
+            const size_t pitch = (size_t)T * M2 * 8;
+            for (int k = 0, t0 = 0; t0 < T && rc == MFS_OK && e == hipSuccess; ++k, t0 += chunk) {
+                a.t_begin = t0;
+                a.t_end = (t0 + chunk < T) ? t0 + chunk : T;
+                e = launch_filter(p, a, s);
+                if (e != hipSuccess) { rc = fail(MFS_EHIP, "kernel launch failed: %s", hipGetErrorString(e)); break; }
+                e = hipEventRecord(cx->ev[k], s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(cx->copy, cx->ev[k], 0);
+                if (e == hipSuccess && out_moments)
+                    e = hipMemcpy2DAsync(out_moments + (size_t)t0 * M2, pitch, d_mom + (size_t)t0 * M2, pitch,
+                                         (size_t)(a.t_end - t0) * M2 * 8, (size_t)B, hipMemcpyDeviceToHost, cx->copy);
+            }
+        }
     }
-    hipFree(d_m0); hipFree(d_mean0); hipFree(d_scale0); hipFree(d_ys); hipFree(d_mom); hipFree(d_means);
-    hipFree(d_scales); hipFree(d_nell); hipFree(d_fn);
-    mfs_plan_1d_destroy(p);
+    auto d2h = [&](void* h, const void* d, size_t bytes) {
+        if (rc == MFS_OK && e == hipSuccess && h && d && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    };
+    d2h(out_means, d_means, (size_t)B * T * 8);
+    d2h(out_scales, d_scales, (size_t)B * T * 8);
+    d2h(out_nell, d_nell, (size_t)B * 8);
+    d2h(out_first_nan, d_fn, (size_t)B * 4);
+    // quiesce both streams whatever happened above: the pool blocks go back when `lease` and `guard` unwind
+    const hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(cx->copy);
     if (rc != MFS_OK) return rc;
+    if (e == hipSuccess) e = (e1 != hipSuccess) ? e1 : e2;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_1d: %s", hipGetErrorString(e));
     return MFS_OK;
 }
@@ -401,13 +458,14 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     const int fpb = ke.waves_per_block * (64 / G);
     const int quad_lds = fpb * (slot >= 3 ? 2 * N : ke.lds_doubles_per_filter) * 8;
     double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_w = nullptr, *d_x = nullptr;
+    mfs::Lease lease(device);
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes); };
-    alloc((void**)&d_ms, (size_t)B * 2 * N * 8);
-    alloc((void**)&d_w, (size_t)B * N * 8);
-    alloc((void**)&d_x, (size_t)B * N * 8);
-    if (mean) alloc((void**)&d_mean, (size_t)B * 8);
-    if (scale) alloc((void**)&d_scale, (size_t)B * 8);
+    auto alloc = [&](double** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block(d, bytes); };
+    alloc(&d_ms, (size_t)B * 2 * N * 8);
+    alloc(&d_w, (size_t)B * N * 8);
+    alloc(&d_x, (size_t)B * N * 8);
+    if (mean) alloc(&d_mean, (size_t)B * 8);
+    if (scale) alloc(&d_scale, (size_t)B * 8);
     if (e == hipSuccess) e = hipMemcpyAsync(d_ms, ms, (size_t)B * 2 * N * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess && mean) e = hipMemcpyAsync(d_mean, mean, (size_t)B * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)B * 8, hipMemcpyHostToDevice, s);
@@ -417,9 +475,51 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_weights, d_w, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(out_nodes, d_x, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d_ms); hipFree(d_mean); hipFree(d_scale); hipFree(d_w); hipFree(d_x);
+    const hipError_t es = hipStreamSynchronize(s);   // always: the blocks go back to the pool on return
+    if (e == hipSuccess) e = es;
     if (e != hipSuccess) return fail(MFS_EHIP, "mfs_quadrature_1d: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the staging pool (pool.hpp), as far as callers see it
+// ---------------------------------------------------------------------------------------------------------------
+int mfs_host_alloc(void** ptr, uint64_t bytes, int device) {
+    if (!ptr) return fail(MFS_EINVAL, "ptr is NULL");
+    *ptr = nullptr;
+    if (device < 0 || device >= mfs::kMaxDevices) return fail(MFS_EINVAL, "device %d outside [0, %d)", device, mfs::kMaxDevices);
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = mfs::device_state(device).pinned.acquire(ptr, (size_t)bytes);
+    if (e != hipSuccess) return fail(MFS_ENOMEM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return MFS_OK;
+}
+
+int mfs_host_free(void* ptr) {
+    if (!ptr) return MFS_OK;
+    for (int d = 0; d < mfs::kMaxDevices; ++d)
+        if (mfs::device_state(d).pinned.release(ptr)) return MFS_OK;
+    return fail(MFS_EINVAL, "pointer was not handed out by mfs_host_alloc");
+}
+
+int mfs_pool_trim(int device) {
+    if (device < 0 || device >= mfs::kMaxDevices) return fail(MFS_EINVAL, "device %d outside [0, %d)", device, mfs::kMaxDevices);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    mfs::DeviceState& st = mfs::device_state(device);
+    st.device.trim();
+    st.pinned.trim();
+    st.contexts.trim();
+    return MFS_OK;
+}
+
+int mfs_pool_stats(int device, uint64_t* device_bytes, uint64_t* pinned_bytes, uint64_t* device_allocs, uint64_t* pinned_allocs) {
+    if (device < 0 || device >= mfs::kMaxDevices) return fail(MFS_EINVAL, "device %d outside [0, %d)", device, mfs::kMaxDevices);
+    mfs::DeviceState& st = mfs::device_state(device);
+    const mfs::PoolCounters dc = st.device.counters(), pc = st.pinned.counters();
+    if (device_bytes) *device_bytes = dc.cached_bytes;
+    if (pinned_bytes) *pinned_bytes = pc.cached_bytes;
+    if (device_allocs) *device_allocs = dc.fresh_allocs;
+    if (pinned_allocs) *pinned_allocs = pc.fresh_allocs;
     return MFS_OK;
 }
 
@@ -629,13 +729,16 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
     if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
     if (B == 0) return MFS_OK;
-    hipStream_t s = (hipStream_t)stream;
     const size_t Z = (size_t)z, nb = m0_batched ? B : 1;
     double *d_m0 = nullptr, *d_mean0 = nullptr, *d_ys = nullptr, *d_mom = nullptr, *d_means = nullptr, *d_nell = nullptr,
            *d_scale0 = nullptr, *d_scales = nullptr;
     int32_t* d_fn = nullptr;
-    hipError_t e = hipSuccess;
-    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 8); };
+    mfs::Lease lease(device);
+    mfs::CallContext* cx = nullptr;
+    hipError_t e = lease.context(&cx);
+    if (e != hipSuccess) return fail(MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
+    hipStream_t s = stream ? (hipStream_t)stream : cx->compute;
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block(d, bytes); };
     auto h2d = [&](void* d, const void* h, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
     };
@@ -665,9 +768,8 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
         d2h(out_nell, d_nell, (size_t)B * 8);
         d2h(out_first_nan, d_fn, (size_t)B * 4);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d_m0); hipFree(d_mean0); hipFree(d_ys); hipFree(d_mom); hipFree(d_means); hipFree(d_nell); hipFree(d_fn);
-    hipFree(d_scale0); hipFree(d_scales);
+    const hipError_t es = hipStreamSynchronize(s);   // always: the pool blocks go back on return
+    if (e == hipSuccess) e = es;
     if (rc != MFS_OK) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
     return MFS_OK;
@@ -683,12 +785,13 @@ extern "C" int mfs_elementary(int which, int n, const double* x, double* out, in
     if (!x || !out) return fail(MFS_EINVAL, "NULL buffer");
     HIP_TRY(hipSetDevice(device));
     double *d_x = nullptr, *d_o = nullptr;
-    hipError_t e = hipMalloc((void**)&d_x, (size_t)n * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_o, (size_t)n * 8);
+    mfs::Lease lease(device);
+    hipError_t e = lease.device_block(&d_x, (size_t)n * 8);
+    if (e == hipSuccess) e = lease.device_block(&d_o, (size_t)n * 8);
     if (e == hipSuccess) e = hipMemcpy(d_x, x, (size_t)n * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = mfs::launch_elementary(which, n, d_x, d_o, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out, d_o, (size_t)n * 8, hipMemcpyDeviceToHost);
-    hipFree(d_x); hipFree(d_o);
+    (void)hipDeviceSynchronize();
     if (e != hipSuccess) return fail(MFS_EHIP, "mfs_elementary: %s", hipGetErrorString(e));
     return MFS_OK;
 }
@@ -710,7 +813,8 @@ extern "C" int mfs_characteristic_1d(int N, int count, const double* ms, const d
     const int G = (gi == 3) ? 8 : (gi == 0) ? 16 : (gi == 1) ? 32 : 64, fpb = 64 / G;
     double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_zs = nullptr, *d_out = nullptr;
     hipError_t e = hipSuccess;
-    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = hipMalloc(d, bytes); };
+    mfs::Lease lease(device);
+    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block((char**)d, bytes); };
     alloc((void**)&d_ms, (size_t)count * 2 * N * 8);
     alloc((void**)&d_zs, (size_t)nz * 8);
     alloc((void**)&d_out, (size_t)count * nz * 16);
@@ -725,8 +829,8 @@ extern "C" int mfs_characteristic_1d(int N, int count, const double* ms, const d
         e = launch(a, (count + fpb - 1) / fpb, fpb * 2 * N * 8, s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)count * nz * 16, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d_ms); hipFree(d_mean); hipFree(d_scale); hipFree(d_zs); hipFree(d_out);
+    const hipError_t es = hipStreamSynchronize(s);   // always: the pool blocks go back on return
+    if (e == hipSuccess) e = es;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_characteristic_1d: %s", hipGetErrorString(e));
     return MFS_OK;
 }

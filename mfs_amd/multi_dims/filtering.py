@@ -140,9 +140,9 @@ def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, de
     model, keep = _model_struct(tables, lik)
     mi32 = np.ascontiguousarray(multi_indices, dtype=np.int32)
     inds32 = np.ascontiguousarray(inds, dtype=np.int32)
-    out_m = np.empty((B, T, z))
-    out_mean = np.empty((B, T, 2)) if mode != 'raw' else None
-    out_scale = np.empty((B, T, 2)) if mode == 'scaled' else None
+    out_m = _lib.pinned_empty((B, T, z), device=device)
+    out_mean = _lib.pinned_empty((B, T, 2), device=device) if mode != 'raw' else None
+    out_scale = _lib.pinned_empty((B, T, 2), device=device) if mode == 'scaled' else None
     out_nell, out_fn = np.empty((B,)), np.empty((B,), dtype=np.int32)
     _lib.check(_lib.lib().mfs_filter_nd(C.byref(model), _lib.MODE[mode], N, T, B, z, _lib.ptr(mi32), _lib.ptr(inds32),
                                         _lib.ptr(ms0), int(batched), _lib.ptr(mean_a), _lib.ptr(scale_a), _lib.ptr(ys2),

@@ -159,9 +159,10 @@ def _run(mode, tables, lik, ms0, mean0, scale0, ys, stable, device=0, want_first
     if not 2 <= N <= _lib.MAX_N:
         raise ValueError(f'N = {N} outside the supported range [2, {_lib.MAX_N}]')
     model, keep = build_model_struct(tables, lik, B)
-    out_m = np.empty((B, T, 2 * N))
-    out_mean = np.empty((B, T)) if mode != 'raw' else None
-    out_scale = np.empty((B, T)) if mode == 'scaled' else None
+    # results land in page-locked memory from the library's pool (PCIe-rate copies; MFS_PINNED_OUTPUTS=0 disables)
+    out_m = _lib.pinned_empty((B, T, 2 * N), device=device)
+    out_mean = _lib.pinned_empty((B, T), device=device) if mode != 'raw' else None
+    out_scale = _lib.pinned_empty((B, T), device=device) if mode == 'scaled' else None
     out_nell = np.empty((B,))
     out_fn = np.empty((B,), dtype=np.int32)
     L = _lib.lib()

@@ -138,3 +138,54 @@ def test_nd_plan_device_pointers_match_host_entry():
     assert rc == _lib.MFS_EINVAL if hasattr(_lib, 'MFS_EINVAL') else rc < 0
     _lib.check(L.mfs_plan_nd_destroy(plan2))
     _lib.check(L.mfs_plan_nd_destroy(plan))
+
+
+def test_pipelined_host_entry_is_bit_identical_and_reuses_the_pool(monkeypatch):
+    """mfs_filter_1d splits T into chunks and copies chunk k's moments out while chunk k + 1 computes (2-D copies into
+    the caller's [B][T][2N] array): the bits are those of one launch, whether the destination is page-locked (the
+    wrappers' default) or ordinary NumPy memory, and a repeated call takes every staging buffer from the pool."""
+    N, T, B = 10, 203, 70          # T not a multiple of the chunk count
+    dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+    _, c, _, mu, _ = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+    ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=5)
+    monkeypatch.setenv('MFS_HOST_CHUNKS', '1')
+    ref = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys, return_first_nan=True)
+    for chunks, pinned in (('7', '1'), ('7', '0'), ('16', '1'), ('203', '1')):
+        monkeypatch.setenv('MFS_HOST_CHUNKS', chunks)
+        monkeypatch.setenv('MFS_PINNED_OUTPUTS', pinned)
+        got = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys, return_first_nan=True)
+        for a, b in zip(ref, got):
+            npt.assert_array_equal(a, b)
+        del got
+    # scaled mode carries one more state variable across chunks
+    s0 = float(np.sqrt(ic.variance))
+    _, _, sc, _, mv = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+    monkeypatch.setenv('MFS_HOST_CHUNKS', '1')
+    ref_s = filtering.moment_filter_scms(sc, mv, pmf, ic.scms, ic.mean, s0, ys)
+    monkeypatch.setenv('MFS_HOST_CHUNKS', '5')
+    got_s = filtering.moment_filter_scms(sc, mv, pmf, ic.scms, ic.mean, s0, ys)
+    for a, b in zip(ref_s, got_s):
+        npt.assert_array_equal(a, b)
+    del ref_s, got_s
+    # steady state: the second and third identical calls allocate nothing new, on the device or in pinned memory
+    monkeypatch.setenv('MFS_HOST_CHUNKS', '4')
+    monkeypatch.setenv('MFS_PINNED_OUTPUTS', '1')
+    out = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys)
+    del out
+    before = _lib.pool_stats(0)
+    for _ in range(2):
+        out = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys)
+        npt.assert_array_equal(out[2], ref[2])
+        del out
+    after = _lib.pool_stats(0)
+    assert after['device_allocs'] == before['device_allocs'] and after['pinned_allocs'] == before['pinned_allocs']
+    assert after['device_bytes'] > 0 and after['pinned_bytes'] >= B * T * 2 * N * 8
+    # results the caller still holds are never recycled under it
+    keep = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys)
+    snapshot = keep[0].copy()
+    other = filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys[::-1].copy())
+    npt.assert_array_equal(keep[0], snapshot)
+    assert not np.shares_memory(keep[0], other[0])
+    del keep, other
+    _lib.check(_lib.lib().mfs_pool_trim(0))
+    assert _lib.pool_stats(0)['device_bytes'] == 0
