@@ -14,10 +14,20 @@ path over the whole batch (B x T filter time-steps), inputs already resident in 
 Hankel matrix loses positive definiteness -- the reference does the same, SURVEY.md section 7 hard part 3) and the
 kernel stops computing for a poisoned replicate, so counting B x T would credit skipped work.  The nominal B x T rate
 is reported next to it as `nominal_value`.
+
+Beside the contract's fields the line carries (rank 0, N = 1 only): `cpu_baseline` (the oracle's C port on the host
+cores, with BASELINE.json's "max |moment err|" per quantity and the first-NaN agreement), `end_to_end_ms` (the
+reference-shaped Python API moment_filter_cms on the same workload, host pointers in and out) and `other_workloads`
+(short runs of BASELINE configs 3, 4 and 5).
+
+Multi-rank runs: exit status 3 (mfs_amd.dist.EXIT_RCCL_FAILED) and `nll_allgather_ok: false` when the NLL all-gather did
+not go through RCCL, unless --allow-host-gather is given; the fallback gather is never inside the timed region.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -27,8 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector fp64 (half the 157.3 TF fp32 vector peak)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X vector fp64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+SIMDS = 1024
+PEAK_CLOCK_GHZ = 2.4
 
 WORKLOADS = {
     # name: (model, N, T, B per GPU, mode, transition)
@@ -39,11 +51,22 @@ WORKLOADS = {
     'benes_bernoulli_N15_T1000_B4096_raw_tme3': ('benes', 15, 1000, 4096, 'raw', 'tme_3'),
     'benes_bernoulli_N15_T1000_B4096_scaled_tme3': ('benes', 15, 1000, 4096, 'scaled', 'tme_3'),
     'well_poisson_N7_T1000_B131072_central_tme_normal2': ('well', 7, 1000, 131072, 'central', 'tme_normal_2'),
+    # BASELINE config 3 (dardel/convergence): OU / Gaussian, exact linear-Gaussian transition
+    'ou_gaussian_N15_T1000_B1024_central': ('ou', 15, 1000, 1024, 'central', 'exact'),
+    'ou_gaussian_N25_T1000_B1024_central': ('ou', 25, 1000, 1024, 'central', 'exact'),
     # BASELINE config 5 (d = 2): per-GPU shard of the 512-replicate batch is set with --B (128 on 4 GPUs)
     'prey_predator_N6_T500_B512_central_tme2': ('prey', 6, 500, 512, 'central', 'tme_2'),
     'prey_predator_N6_T500_B512_central_tme_normal2': ('prey', 6, 500, 512, 'central', 'tme_normal_2'),
 }
 DEFAULT_WORKLOAD = 'benes_bernoulli_N15_T1000_B4096_central_tme3'
+# (workload, B override, label): short runs reported under `other_workloads` by the default single-GPU run
+OTHER_WORKLOADS = [
+    ('ou_gaussian_N15_T1000_B1024_central', 0, 'config3_N15'),
+    ('ou_gaussian_N25_T1000_B1024_central', 0, 'config3_N25'),
+    ('well_poisson_N7_T1000_B131072_central_tme_normal2', 0, 'config4_shard_B131072'),
+    ('prey_predator_N6_T500_B512_central_tme2', 0, 'config5_B512'),
+    ('prey_predator_N6_T500_B512_central_tme2', 128, 'config5_4gpu_shard_B128'),
+]
 
 
 def parse_args():
@@ -58,36 +81,334 @@ def parse_args():
     p.add_argument('--no-moments', action='store_true', help='NLL only: do not stream the (B, T, 2N) moments out')
     p.add_argument('--cpu-seconds', type=float, default=12., help='target wall time of the cpu_baseline sample')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-end-to-end', action='store_true', help='skip the reference-shaped host API timing')
+    p.add_argument('--no-other-workloads', action='store_true', help='skip the short runs of configs 3 / 4 / 5')
+    p.add_argument('--allow-host-gather', action='store_true',
+                   help='multi-rank: exit 0 even if the NLL all-gather fell back from RCCL to the host route')
     return p.parse_args()
 
 
-def build_model(model, N, transition, B, rng):
-    from mfs_amd.one_dim import moments, ss_models
-    if model == 'benes':
-        dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
-        theta = None
-    else:
-        dt, _, _, ic, drift0, dispersion, _, pmf0, _ = ss_models.well_poisson(3., N)
-        # parameter grid of BASELINE config 4 (theta in [0.5, 6]^2), one point per replicate
-        p1 = rng.uniform(0.5, 6., size=B)
-        p2 = rng.uniform(0.5, 6., size=B)
-        theta = (p1, p2)
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+class Workload1D:
+    """Model closures, synthetic measurements and device-resident buffers of one 1-D workload on this rank."""
 
-        def drift(x):
-            return drift0(x, p1)
+    def __init__(self, name, B, T, rank, device, fast_data=False):
+        from mfs_amd import _lib, synth, stats
+        from mfs_amd.one_dim import filtering, moments, ss_models
+        self.name = name
+        self.model, self.N, T0, B0, self.mode, self.transition = WORKLOADS[name]
+        self.B, self.T = B or B0, T or T0
+        self.full_size = (self.B == B0 and self.T == T0)
+        N, B, T = self.N, self.B, self.T
+        rng = np.random.default_rng(1234 + rank)
+        self.theta = None
+        sub = 2 if fast_data else 10    # Euler sub-steps of the synthetic paths (bench-only data: cheaper generation)
+        if self.model == 'benes':
+            dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+            self.ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=100 + rank, substeps=sub)
+        elif self.model == 'well':
+            dt, _, _, ic, drift0, dispersion, _, pmf0, _ = ss_models.well_poisson(3., N)
+            # parameter grid of BASELINE config 4 (theta in [0.5, 6]^2), one point per replicate
+            p1, p2 = rng.uniform(0.5, 6., size=B), rng.uniform(0.5, 6., size=B)
+            self.theta = (p1, p2)
+            drift, pmf = (lambda x: drift0(x, p1)), (lambda y, x: pmf0(y, x, p2))
+            nb = min(B, 4096) if fast_data else B    # short runs: 4096 measurement sets tiled over the theta grid
+            ys, _ = synth.well_poisson_batch(nb, T, p1=3., p2=3., dt=dt, seed=100 + rank, substeps=sub)
+            self.ys = np.ascontiguousarray(np.tile(ys, (-(-B // nb), 1))[:B])
+        else:   # 'ou': dardel/convergence/convergence_mf.py:32-61 -- dt = 0.1, ell = 1, sigma = 0.5, R = 1, x0 ~ N(0, sigma^2)
+            import math
+            from mfs_amd.utils import GaussianSum1D
+            dt_ou, ell, sigma = 0.1, 1., 0.5
+            F, Sigma = math.exp(-dt_ou / ell), sigma ** 2 * (1 - math.exp(-2 * dt_ou / ell))
+            self.ys, _ = synth.ou_gaussian_batch(B, T, dt=dt_ou, ell=ell, sigma=sigma, seed=100 + rank)
+            ic = GaussianSum1D.new(means=[0.], variances=[sigma ** 2], weights=[1.], N=N)
+            pmf = lambda y, x: stats.norm_pdf(y, x, 1.)   # noqa: E731
+        if self.model == 'ou':
+            fns = moments.sde_cond_moments_normal(lambda x: F * x, lambda x: Sigma)
+        else:
+            kind, order = self.transition.rsplit('_', 1)
+            if kind == 'tme':
+                fns = moments.sde_cond_moments_tme(drift, dispersion, dt, int(order))
+            else:
+                fns = moments.sde_cond_moments_tme_normal(drift, dispersion, dt, int(order), N)
+        self.ic, self.fns, self.pmf = ic, fns, pmf
+        mean_fn = fns[3] if self.mode == 'central' else fns[4] if self.mode == 'scaled' else None
+        self.tables, self.lik = filtering.trace_model(self.mode, fns[{'raw': 0, 'central': 1, 'scaled': 2}[self.mode]],
+                                                      mean_fn, pmf)
+        self.mstruct, self._keep = filtering.build_model_struct(self.tables, self.lik, B)
+        self.m0 = {'raw': ic.rms, 'central': ic.cms, 'scaled': ic.scms}[self.mode]
+        self.device = device
+        self.z = 2 * N
 
-        def pmf(y, x):
-            return pmf0(y, x, p2)
-    kind, order = transition.rsplit('_', 1)
-    if kind == 'tme':
-        fns = moments.sde_cond_moments_tme(drift, dispersion, dt, int(order))
-    elif kind == 'tme_normal':
-        fns = moments.sde_cond_moments_tme_normal(drift, dispersion, dt, int(order), N)
-    else:
-        raise ValueError(transition)
-    return dt, ic, fns, pmf, theta
+    def upload(self, want_moments, chunk):
+        import ctypes as C
+        from mfs_amd import _lib
+        L = _lib.lib()
+        B, T, N = self.B, self.T, self.N
+        self.d_m0 = _lib.DeviceBuffer.from_array(self.m0)
+        self.d_mean0 = _lib.DeviceBuffer.from_array(np.array([self.ic.mean], dtype=np.float64))
+        self.d_scale0 = _lib.DeviceBuffer.from_array(np.array([np.sqrt(self.ic.variance)]))
+        self.d_ys = _lib.DeviceBuffer.from_array(self.ys)
+        self.d_mom = _lib.DeviceBuffer(B * T * 2 * N * 8) if want_moments else None
+        self.d_means = _lib.DeviceBuffer(B * T * 8)
+        self.d_scales = _lib.DeviceBuffer(B * T * 8) if self.mode == 'scaled' else None
+        self.d_nell = _lib.DeviceBuffer(B * 8)
+        self.d_fn = _lib.DeviceBuffer(B * 4)
+        self.plan = C.c_void_p()
+        _lib.check(L.mfs_plan_1d_create(C.byref(self.plan), C.byref(self.mstruct), _lib.MODE[self.mode], N, T, B, 0,
+                                        chunk, self.device))
+        geo = [C.c_int() for _ in range(4)]
+        _lib.check(L.mfs_plan_1d_geometry(self.plan, *[C.byref(g) for g in geo]))
+        self.geometry = {'lanes_per_filter': geo[0].value, 'filters_per_block': geo[1].value, 'grid': geo[2].value,
+                         'lds_bytes_per_block': geo[3].value}
+        self.kernel = 'mfs::filter1d_fast_kernel'
+
+    def launch(self, stream):
+        from mfs_amd import _lib
+        _lib.check(_lib.lib().mfs_plan_1d_run(self.plan, self.d_m0.ptr, 0, self.d_mean0.ptr, self.d_scale0.ptr,
+                                              self.d_ys.ptr, self.d_mom.ptr if self.d_mom else None, self.d_means.ptr,
+                                              self.d_scales.ptr if self.d_scales else None, self.d_nell.ptr,
+                                              self.d_fn.ptr, stream))
+
+    def release(self):
+        from mfs_amd import _lib
+        _lib.check(_lib.lib().mfs_plan_1d_destroy(self.plan))
+        for b in (self.d_m0, self.d_mean0, self.d_scale0, self.d_ys, self.d_mom, self.d_means, self.d_scales,
+                  self.d_nell, self.d_fn):
+            if b is not None:
+                b.free()
+
+    def algorithmic_bytes(self, live_steps, want_moments):
+        # SURVEY.md section 8d: per live filter-step one y in, 2N moments + mean (+ scale) out; per filter 2N + 1
+        extra = {'raw': 1, 'central': 2, 'scaled': 3}[self.mode]
+        per_step = 8 * (2 * self.N + extra) if want_moments else 8 * 2
+        return live_steps * per_step + self.B * (8 * 2 * self.N + 8)
+
+    def host_api_call(self):
+        """The reference-shaped entry point (mfs/one_dim/filtering.py:92-98 signature), host arrays in and out."""
+        from mfs_amd.one_dim import filtering
+        ic, f = self.ic, self.fns
+        if self.mode == 'raw':
+            return filtering.moment_filter_rms(f[0], self.pmf, ic.rms, self.ys, device=self.device)
+        if self.mode == 'central':
+            return filtering.moment_filter_cms(f[1], f[3], self.pmf, ic.cms, ic.mean, self.ys, device=self.device)
+        return filtering.moment_filter_scms(f[2], f[4], self.pmf, ic.scms, ic.mean, float(np.sqrt(ic.variance)),
+                                            self.ys, device=self.device)
 
 
+class WorkloadND:
+    """BASELINE config 5: the d = 2 prey--predator filter through the device-pointer N-D plan."""
+
+    def __init__(self, name, B, T, rank, device, fast_data=False):
+        from mfs_amd import synth
+        from mfs_amd.multi_dims import filtering, moments, ss_models
+        from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+            gram_and_hankel_indices_graded_lexico
+        self.name = name
+        self.model, self.N, T0, B0, self.mode, self.transition = WORKLOADS[name]
+        self.B, self.T = B or B0, T or T0
+        self.full_size = (self.B == B0 and self.T == T0)
+        N = self.N
+        self.mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+        self.inds = gram_and_hankel_indices_graded_lexico(N, 2)
+        self.z = self.mi.shape[0]
+        dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(self.mi)
+        kind, order = self.transition.rsplit('_', 1)
+        if kind == 'tme':
+            self.fns, self.sig = moments.sde_cond_moments_tme(drift, disp, dt, int(order)), 'multi-index'
+        else:
+            self.fns, self.sig = moments.sde_cond_moments_tme_normal(drift, disp, dt, int(order), self.mi), 'index'
+        self.ys, _ = synth.prey_predator_batch(self.B, self.T, dt, seed=100 + rank, substeps=4 if fast_data else 20)
+        self.gs, self.pmf, self.device = gs, pmf, device
+        self.filtering = filtering
+        self.theta = None
+
+    def upload(self, want_moments, chunk):
+        import ctypes as C
+        from mfs_amd import _lib
+        L = _lib.lib()
+        f, mode, gs, mi, B, T, z = self.filtering, self.mode, self.gs, self.mi, self.B, self.T, self.z
+        tables = f._trace_transition((self.fns[{'raw': 0, 'central': 1, 'scaled': 2}[mode]], self.sig), mode,
+                                     (mi, self.inds))
+        lik = f._trace_likelihood(self.pmf, 2)
+        self.mstruct, self._keep = f._model_struct(tables, lik)
+        scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))
+        m0 = {'raw': gs.rms, 'central': gs.cms, 'scaled': gs.cms / np.prod(scale0 ** mi, axis=-1)}[mode]
+        self.d_m0 = _lib.DeviceBuffer.from_array(np.ascontiguousarray(m0))
+        self.d_mean0 = _lib.DeviceBuffer.from_array(np.ascontiguousarray(gs.mean, dtype=np.float64))
+        self.d_scale0 = _lib.DeviceBuffer.from_array(scale0)
+        self.d_ys = _lib.DeviceBuffer.from_array(self.ys)
+        self.d_mom = _lib.DeviceBuffer(B * T * z * 8) if want_moments else None
+        self.d_means = _lib.DeviceBuffer(B * T * 2 * 8)
+        self.d_scales = _lib.DeviceBuffer(B * T * 2 * 8)
+        self.d_nell = _lib.DeviceBuffer(B * 8)
+        self.d_fn = _lib.DeviceBuffer(B * 4)
+        self._mi32 = np.ascontiguousarray(mi, dtype=np.int32)
+        self._inds32 = np.ascontiguousarray(self.inds, dtype=np.int32)
+        self.plan = C.c_void_p()
+        _lib.check(L.mfs_plan_nd_create(C.byref(self.plan), C.byref(self.mstruct), _lib.MODE[mode], self.N, T, B, z,
+                                        _lib.ptr(self._mi32), _lib.ptr(self._inds32), 0, self.device))
+        geo = [C.c_int() for _ in range(3)]
+        _lib.check(L.mfs_plan_nd_geometry(self.plan, *[C.byref(g) for g in geo]))
+        self.geometry = {'threads_per_filter': geo[0].value, 'grid': geo[1].value, 'lds_bytes_per_block': geo[2].value,
+                         'd': 2, 'z': int(z)}
+        self.kernel = 'mfs::filternd_kernel'
+
+    def launch(self, stream):
+        from mfs_amd import _lib
+        _lib.check(_lib.lib().mfs_plan_nd_run(self.plan, self.d_m0.ptr, 0, self.d_mean0.ptr, self.d_scale0.ptr,
+                                              self.d_ys.ptr, self.d_mom.ptr if self.d_mom else None, self.d_means.ptr,
+                                              self.d_scales.ptr, self.d_nell.ptr, self.d_fn.ptr, stream))
+
+    def release(self):
+        from mfs_amd import _lib
+        _lib.check(_lib.lib().mfs_plan_nd_destroy(self.plan))
+        for b in (self.d_m0, self.d_mean0, self.d_scale0, self.d_ys, self.d_mom, self.d_means, self.d_scales,
+                  self.d_nell, self.d_fn):
+            if b is not None:
+                b.free()
+
+    def algorithmic_bytes(self, live_steps, want_moments):
+        extra = {'raw': 1, 'central': 3, 'scaled': 5}[self.mode]
+        per_step = 8 * (self.z + extra) if want_moments else 8 * 2
+        return live_steps * per_step + self.B * 8 * (self.z + 3)
+
+    def host_api_call(self):
+        f, gs = self.filtering, self.gs
+        if self.mode == 'central':
+            return f.moment_filter_nd_cms((self.fns[1], self.sig), self.fns[3], self.pmf, self.ys, (self.mi, self.inds),
+                                          gs.cms, gs.mean, device=self.device)
+        return f.moment_filter_nd_rms((self.fns[0], self.sig), self.pmf, self.ys, (self.mi, self.inds), gs.rms,
+                                      device=self.device)
+
+
+def make_workload(name, B, T, rank, device, fast_data=False):
+    cls = WorkloadND if WORKLOADS[name][0] == 'prey' else Workload1D
+    return cls(name, B, T, rank, device, fast_data)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the timed region
+# ---------------------------------------------------------------------------------------------------------------------
+def timed_passes(w, comm, steps, warmup, want_moments, chunk):
+    """W untimed + K timed passes of the hot path, barrier + device sync on both sides, max over ranks; the NLL
+    all-gather rides on the launch stream (RCCL) -- a host-route fallback is done once, after the clock has stopped."""
+    import ctypes as C
+    from mfs_amd import _lib
+    L = _lib.lib()
+    w.upload(want_moments, chunk)
+    d_nell_all = _lib.DeviceBuffer(w.B * 8 * comm.world)
+    stream = C.c_void_p()
+    _lib.check(L.mfs_stream_create(C.byref(stream)))
+    ev = [C.c_void_p() for _ in range(2 * max(steps, 1))]
+    for e in ev:
+        _lib.check(L.mfs_event_create(C.byref(e)))
+    gather_in_loop = not comm.degraded
+
+    def one_pass(i=None):
+        if i is not None:
+            _lib.check(L.mfs_event_record(ev[2 * i], stream))
+        w.launch(stream)
+        if i is not None:
+            _lib.check(L.mfs_event_record(ev[2 * i + 1], stream))
+        if gather_in_loop:
+            comm.allgather_nell(w.d_nell, d_nell_all, w.B, stream)  # RCCL over xGMI when world > 1; device copy otherwise
+
+    for _ in range(warmup):
+        one_pass()
+    _lib.check(L.mfs_stream_synchronize(stream))
+    comm.barrier()
+    _lib.check(L.mfs_device_synchronize())
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one_pass(i)
+    _lib.check(L.mfs_stream_synchronize(stream))
+    _lib.check(L.mfs_device_synchronize())
+    comm.barrier()
+    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
+    if not gather_in_loop:
+        comm.allgather_nell(w.d_nell, d_nell_all, w.B, stream)      # host route (reported as a failure), untimed
+        _lib.check(L.mfs_stream_synchronize(stream))
+
+    kern_ms = []
+    for i in range(steps):
+        ms = C.c_float()
+        _lib.check(L.mfs_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
+        kern_ms.append(ms.value)
+    first_nan = w.d_fn.to_array((w.B,), np.int32)
+    nell = w.d_nell.to_array((w.B,))
+    nell_all = d_nell_all.to_array((comm.world * w.B,))
+    res = {'elapsed': elapsed, 'kern_ms': kern_ms, 'first_nan': first_nan, 'nell': nell,
+           'live_steps': int(np.where(first_nan >= 0, first_nan + 1, w.T).sum()),
+           'alive': int((first_nan < 0).sum()),
+           'gather_matches': bool(np.array_equal(nell_all[comm.rank * w.B:(comm.rank + 1) * w.B], nell, equal_nan=True))}
+    for e in ev:
+        _lib.check(L.mfs_event_destroy(e))
+    _lib.check(L.mfs_stream_destroy(stream))
+    d_nell_all.free()
+    return res
+
+
+def natural(path):   # r01_v9 before r01_v10, r01 before r02
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', path)]
+
+
+def recorded_pmc(workload, moments_streamed=True):
+    """The newest committed counter summary of this workload (counters cannot be read from inside the process; they are
+    collected with rocprofv3 --pmc in separate passes, condensed by tools/pmc_summary.py and committed under profiles/)."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc*.json')), key=natural):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get('workload') == workload and moments_streamed and rec.get('B_override') in (None, 0):
+            best = dict(rec, source=os.path.relpath(path, ROOT))
+    return best
+
+
+def executed_work(pmc, T, kern_ms):
+    """Utilisation of the vector ALU from the committed counters (per launch) and this run's launch time.  What the
+    kernel EXECUTED, not a flop model of the reference's dense algorithm."""
+    if not pmc or 'sq' not in pmc:
+        return None
+    sq = pmc['sq']
+    out = {'source': pmc['source']}
+    if 'SQ_INSTS_VALU' in sq and 'SQ_WAVE_CYCLES' in sq:
+        # SQ_WAVE_CYCLES counts quad-cycles (MI355X_MICROARCH.md), a wave64 VALU instruction occupies the SIMD for 4 clocks
+        out['valu_issue_occupancy_per_wave'] = sq['SQ_INSTS_VALU'] / sq['SQ_WAVE_CYCLES']
+        out['valu_insts_per_wave_step'] = sq['SQ_INSTS_VALU'] / sq.get('SQ_WAVES', 1.) / T
+        # chip level: wave-instructions per second against SIMDS x clock / 4
+        rate = sq['SQ_INSTS_VALU'] / (kern_ms * 1e-3)
+        out['valu_wave_insts_per_s'] = rate
+        out['valu_issue_fraction_of_chip_peak'] = rate / (SIMDS * PEAK_CLOCK_GHZ * 1e9 / 4)
+    f64 = {k: sq[k] for k in ('SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64',
+                              'SQ_INSTS_VALU_TRANS_F64') if k in sq}
+    if 'SQ_INSTS_VALU_FMA_F64' in f64:
+        flops = 64. * (2 * f64['SQ_INSTS_VALU_FMA_F64'] + f64.get('SQ_INSTS_VALU_MUL_F64', 0.) +
+                       f64.get('SQ_INSTS_VALU_ADD_F64', 0.) + f64.get('SQ_INSTS_VALU_TRANS_F64', 0.))
+        out['fp64_insts'] = f64
+        out['fp64_tflops_executed'] = flops / (kern_ms * 1e-3) / 1e12      # 64 lanes per wave-instruction, idle lanes included
+        out['fp64_fraction_of_vector_peak'] = out['fp64_tflops_executed'] / FP64_VALU_PEAK_TFLOPS
+    if 'wait_fraction_of_wave_cycles' in pmc:
+        out['wait_fraction_of_wave_cycles'] = pmc['wait_fraction_of_wave_cycles']
+    return out
+
+
+def summarise(w, res, steps, world, want_moments, live_total=None):
+    kern_ms = float(np.mean(res['kern_ms'])) if res['kern_ms'] else float('nan')
+    live_total = res['live_steps'] if live_total is None else live_total
+    algo = w.algorithmic_bytes(res['live_steps'], want_moments)
+    return {'ms_per_step': res['elapsed'] / steps * 1e3, 'kernel_ms': kern_ms,
+            'value': live_total * steps / res['elapsed'], 'nominal_value': world * w.B * w.T * steps / res['elapsed'],
+            'live_fraction': live_total / (world * w.B * w.T), 'algorithmic_bytes_per_launch': algo,
+            'hbm_gbs': algo / (kern_ms * 1e-3) / 1e9}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
@@ -98,267 +419,135 @@ def main():
             raise SystemExit('launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N bench.py')
         args.gpus = world
 
-    import ctypes as C
-    from mfs_amd import _lib, synth, dist
-    from mfs_amd.one_dim import filtering
-
-    model, N, T, B, mode, transition = WORKLOADS[args.workload]
-    B = args.B or B
-    T = args.T or T
+    from mfs_amd import _lib, dist
     L = _lib.lib()
-    if model == 'prey':
-        return main_nd(args, rank, local_rank, world, N, T, B, mode, transition)
     # one GPU per rank; on a box with fewer GPUs than ranks (rehearsals only) ranks share devices and RCCL, which
-    # refuses duplicate GPUs, falls back to the reported host gather
+    # refuses duplicate GPUs, fails: reported, and the exit status says so
     device = local_rank % max(_lib.device_count(), 1)
     comm = dist.Communicator.from_env(device=device)  # TCP control plane (mfs_amd/rdzv.py) + RCCL for the NLL gather
     _lib.check(L.mfs_set_device(device))
+    want_moments = not args.no_moments
 
-    # ---- synthetic inputs for this rank's shard (seeded per rank), uploaded before the timed region
-    rng = np.random.default_rng(1234 + rank)
-    dt, ic, fns, pmf, theta = build_model(model, N, transition, B, rng)
-    if model == 'benes':
-        ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=100 + rank)
-    else:
-        ys, _ = synth.well_poisson_batch(B, T, p1=3., p2=3., dt=dt, seed=100 + rank)
-    tables, lik = filtering.trace_model(mode, fns[{'raw': 0, 'central': 1, 'scaled': 2}[mode]],
-                                        fns[3] if mode == 'central' else None, pmf)
-    mstruct, keep = filtering.build_model_struct(tables, lik, B)
-    m0 = {'raw': ic.rms, 'central': ic.cms, 'scaled': ic.scms}[mode]
-    d_m0 = _lib.DeviceBuffer.from_array(m0)
-    d_mean0 = _lib.DeviceBuffer.from_array(np.array([ic.mean]))
-    d_scale0 = _lib.DeviceBuffer.from_array(np.array([np.sqrt(ic.variance)]))
-    d_ys = _lib.DeviceBuffer.from_array(ys)
-    d_mom = None if args.no_moments else _lib.DeviceBuffer(B * T * 2 * N * 8)
-    d_means = _lib.DeviceBuffer(B * T * 8)
-    d_nell = _lib.DeviceBuffer(B * 8)
-    d_fn = _lib.DeviceBuffer(B * 4)
-    d_nell_all = _lib.DeviceBuffer(B * 8 * world)
-
-    plan = C.c_void_p()
-    _lib.check(L.mfs_plan_1d_create(C.byref(plan), C.byref(mstruct), _lib.MODE[mode], N, T, B, 0, args.chunk,
-                                    device))
-    geo = [C.c_int() for _ in range(4)]
-    _lib.check(L.mfs_plan_1d_geometry(plan, *[C.byref(g) for g in geo]))
-    stream = C.c_void_p()
-    _lib.check(L.mfs_stream_create(C.byref(stream)))
-    ev = [C.c_void_p() for _ in range(2 * max(args.steps, 1))]
-    for e in ev:
-        _lib.check(L.mfs_event_create(C.byref(e)))
-
-    def one_pass(i=None):
-        if i is not None:
-            _lib.check(L.mfs_event_record(ev[2 * i], stream))
-        _lib.check(L.mfs_plan_1d_run(plan, d_m0.ptr, 0, d_mean0.ptr, d_scale0.ptr, d_ys.ptr,
-                                     d_mom.ptr if d_mom else None, d_means.ptr, None, d_nell.ptr, d_fn.ptr, stream))
-        if i is not None:
-            _lib.check(L.mfs_event_record(ev[2 * i + 1], stream))
-        comm.allgather_nell(d_nell, d_nell_all, B, stream)  # RCCL over xGMI when world > 1; no-op copy otherwise
-
-    for _ in range(args.warmup):
-        one_pass()
-    _lib.check(L.mfs_stream_synchronize(stream))
-    comm.barrier()
-    _lib.check(L.mfs_device_synchronize())
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_pass(i)
-    _lib.check(L.mfs_stream_synchronize(stream))
-    _lib.check(L.mfs_device_synchronize())
-    comm.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = comm.max_over_ranks(elapsed)
-
-    # ---- per-launch kernel time from HIP events on the launch stream
-    kern_ms = []
-    for i in range(args.steps):
-        ms = C.c_float()
-        _lib.check(L.mfs_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
-        kern_ms.append(ms.value)
-    kern_ms_avg = float(np.mean(kern_ms)) if kern_ms else float('nan')
-
-    first_nan = d_fn.to_array((B,), np.int32)
-    nell = d_nell.to_array((B,))
-    live_steps = int(np.where(first_nan >= 0, first_nan + 1, T).sum())
-    live_total = comm.sum_over_ranks(live_steps)
-    alive_total = comm.sum_over_ranks(int((first_nan < 0).sum()))
-    nell_all = d_nell_all.to_array((world * B,))
-    gather_ok = bool(np.array_equal(nell_all[rank * B:(rank + 1) * B], nell, equal_nan=True))
+    w = make_workload(args.workload, args.B, args.T, rank, device)
+    res = timed_passes(w, comm, args.steps, args.warmup, want_moments, args.chunk)
+    live_total = comm.sum_over_ranks(res['live_steps'])
+    alive_total = comm.sum_over_ranks(res['alive'])
+    gather_ok = all(comm._allgather_obj(bool(res['gather_matches']))) and not comm.degraded
+    exit_code = 0
 
     if rank == 0:
-        nominal_steps = world * B * T
-        value = live_total * args.steps / elapsed
-        nominal = nominal_steps * args.steps / elapsed
-        # algorithmic HBM bytes per launch: per live filter-step one y in, 2N moments + mean out
-        per_step = 8 * (2 * N + (2 if mode != 'raw' else 1)) if d_mom else 8 * 2
-        algo_bytes = live_steps * per_step + B * (8 * 2 * N + 8)
-        hbm_gbs = algo_bytes / (kern_ms_avg * 1e-3) / 1e9
-        M = int(transition.rsplit('_', 1)[1])
-        flops_step = 22.7 * N ** 3 + (8 * M + 12) * N ** 2
-        tflops = live_steps * flops_step / (kern_ms_avg * 1e-3) / 1e12
-        # (the recorded counters belong to the workload's own size: no figure for --B / --T overrides)
-        full_size = (B == WORKLOADS[args.workload][3] and T == WORKLOADS[args.workload][2])
-        traffic = recorded_hbm_traffic(args.workload, d_mom is not None) if full_size else None
+        s = summarise(w, res, args.steps, world, want_moments, live_total)
+        pmc = recorded_pmc(args.workload, want_moments) if w.full_size else None
+        traffic = pmc.get('hbm_bytes_per_launch') if pmc else None
+        work = executed_work(pmc, w.T, s['kernel_ms'])
+        hbm = {'achieved': s['hbm_gbs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s['hbm_gbs'] / HBM_PEAK_GBS,
+               'algorithmic_bytes_per_launch': s['algorithmic_bytes_per_launch'],
+               'note': 'reported because BASELINE.json asks for the HBM fraction; ~1 % by construction (SURVEY 8d)'}
+        roofline = {'kernel': w.kernel, 'avg_launch_ms': s['kernel_ms'], 'traffic': traffic,
+                    'traffic_source': (pmc['source'] + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, '
+                                       'FETCH_SIZE x2 on gfx950)') if traffic else None,
+                    'algorithmic_bytes_per_launch': s['algorithmic_bytes_per_launch'], 'hbm': hbm}
+        if work and 'fp64_tflops_executed' in work:
+            # the bound of this path is the fp64 vector ALU (issue + dependent-instruction latency), not HBM, not MFMA
+            roofline.update({'bound': 'valu_fp64', 'achieved': work['fp64_tflops_executed'],
+                             'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': work['fp64_fraction_of_vector_peak'],
+                             'basis': 'fp64 flops EXECUTED per launch (SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 x 64 lanes, '
+                                      'FMA = 2) from the committed counters / this run\'s launch time'})
+        else:
+            roofline.update({'bound': 'hbm', 'achieved': hbm['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                             'frac': hbm['frac'],
+                             'note': 'no fp64 instruction counters recorded for this workload: HBM roofline only; the '
+                                     'kernel is bound by fp64 VALU issue + dependency latency'})
+        roofline['valu'] = work
         out = {
-            'metric': 'filter time-steps/sec', 'value': value, 'unit': 'filter-steps/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'metric': 'filter time-steps/sec', 'value': s['value'], 'unit': 'filter-steps/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': s['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'model': None, 'N': N, 'T': T, 'replicates_per_gpu': B,
-                       'mode': mode, 'transition': transition, 'parallelism': f'replicate-sharded x{world}',
-                       'lanes_per_filter': geo[0].value, 'filters_per_block': geo[1].value, 'grid': geo[2].value,
-                       'lds_bytes_per_block': geo[3].value, 'chunk': args.chunk or T,
-                       'moments_streamed_out': d_mom is not None},
-            'nominal_value': nominal, 'live_fraction': live_total / nominal_steps,
-            'replicates_alive_at_T': alive_total, 'replicates': world * B, 'nll_allgather_ok': gather_ok,
+            'config': dict({'workload': args.workload, 'model': None, 'N': w.N, 'T': w.T, 'replicates_per_gpu': w.B,
+                            'mode': w.mode, 'transition': w.transition, 'parallelism': f'replicate-sharded x{world}',
+                            'chunk': args.chunk or w.T, 'moments_streamed_out': want_moments}, **w.geometry),
+            'nominal_value': s['nominal_value'], 'live_fraction': s['live_fraction'],
+            'replicates_alive_at_T': alive_total, 'replicates': world * w.B,
+            'nll_allgather_ok': bool(gather_ok),
             'nll_allgather': ('rccl ncclAllGather' if comm.data == 'rccl' and world > 1 else
-                              'single rank: device copy' if world == 1 else f'host fallback: {comm.rccl_error}'),
-            'target_1e6_steps_per_s_met': bool(value >= 1e6 * world),
-            'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'mfs::filter1d_fast_kernel', 'avg_launch_ms': kern_ms_avg,
-                         'traffic_source': 'profiles/*/pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
-                                           'passes, FETCH_SIZE x2 on gfx950)' if traffic else None,
-                         'algorithmic_bytes_per_launch': algo_bytes,
-                         'note': 'latency/VALU-bound fp64 recursion, not HBM-bound: see valu_fp64'},
-            'valu_fp64': {'achieved': tflops, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                          'frac': tflops / FP64_VALU_PEAK_TFLOPS, 'algorithmic_flops_per_filter_step': flops_step},
+                              'single rank: device copy' if world == 1 else
+                              f'FAILED, host fallback outside the timed region: {comm.rccl_error}'),
+            'target_1e6_steps_per_s_met': bool(s['value'] >= 1e6 * world),
+            'roofline': roofline,
         }
-        if not args.no_cpu_baseline and world == 1:  # contract: the CPU baseline is a rank-0, N = 1 measurement
-            out['cpu_baseline'] = cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, nell, first_nan)
-        print(json.dumps(out))
-    comm.close()
-
-
-def main_nd(args, rank, local_rank, world, N, T, B, mode, transition):
-    """BASELINE config 5: the d = 2 prey--predator filter through the device-pointer N-D plan."""
-    import ctypes as C
-    from mfs_amd import _lib, synth, dist
-    from mfs_amd.multi_dims import filtering, moments, ss_models
-    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
-        gram_and_hankel_indices_graded_lexico
-    L = _lib.lib()
-    device = local_rank % max(_lib.device_count(), 1)
-    comm = dist.Communicator.from_env(device=device)
-    _lib.check(L.mfs_set_device(device))
-    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
-    inds = gram_and_hankel_indices_graded_lexico(N, 2)
-    z = mi.shape[0]
-    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
-    kind, order = transition.rsplit('_', 1)
-    if kind == 'tme':
-        fns, sig = moments.sde_cond_moments_tme(drift, disp, dt, int(order)), 'multi-index'
+        if world == 1:
+            if not args.no_cpu_baseline:
+                try:
+                    out['cpu_baseline'] = (cpu_baseline_nd(args, w, res) if isinstance(w, WorkloadND)
+                                           else cpu_baseline(args, w, res))
+                except Exception as e:   # noqa: BLE001 -- a failing checker must not lose the measurement
+                    out['cpu_baseline'] = {'error': repr(e)}
+            if not args.no_end_to_end:
+                out.update(end_to_end(w))
+        w.release()
+        if world == 1 and not args.no_other_workloads and args.workload == DEFAULT_WORKLOAD and w.full_size:
+            out['other_workloads'] = other_workloads(comm, device)
+        print(json.dumps(out), flush=True)
     else:
-        fns, sig = moments.sde_cond_moments_tme_normal(drift, disp, dt, int(order), mi), 'index'
-    ys, _ = synth.prey_predator_batch(B, T, dt, seed=100 + rank)
-    tables = filtering._trace_transition((fns[{'raw': 0, 'central': 1, 'scaled': 2}[mode]], sig), mode, (mi, inds))
-    lik = filtering._trace_likelihood(pmf, 2)
-    mstruct, keep = filtering._model_struct(tables, lik)
-    scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))
-    m0 = {'raw': gs.rms, 'central': gs.cms, 'scaled': gs.cms / np.prod(scale0 ** mi, axis=-1)}[mode]
-    d_m0 = _lib.DeviceBuffer.from_array(np.ascontiguousarray(m0))
-    d_mean0 = _lib.DeviceBuffer.from_array(np.ascontiguousarray(gs.mean, dtype=np.float64))
-    d_scale0 = _lib.DeviceBuffer.from_array(scale0)
-    d_ys = _lib.DeviceBuffer.from_array(ys)
-    d_mom = None if args.no_moments else _lib.DeviceBuffer(B * T * z * 8)
-    d_means = _lib.DeviceBuffer(B * T * 2 * 8)
-    d_scales = _lib.DeviceBuffer(B * T * 2 * 8)
-    d_nell = _lib.DeviceBuffer(B * 8)
-    d_fn = _lib.DeviceBuffer(B * 4)
-    d_nell_all = _lib.DeviceBuffer(B * 8 * world)
-    mi32 = np.ascontiguousarray(mi, dtype=np.int32)
-    inds32 = np.ascontiguousarray(inds, dtype=np.int32)
-    plan = C.c_void_p()
-    _lib.check(L.mfs_plan_nd_create(C.byref(plan), C.byref(mstruct), _lib.MODE[mode], N, T, B, z, _lib.ptr(mi32),
-                                    _lib.ptr(inds32), 0, device))
-    geo = [C.c_int() for _ in range(3)]
-    _lib.check(L.mfs_plan_nd_geometry(plan, *[C.byref(g) for g in geo]))
-    stream = C.c_void_p()
-    _lib.check(L.mfs_stream_create(C.byref(stream)))
-    ev = [C.c_void_p() for _ in range(2 * max(args.steps, 1))]
-    for e in ev:
-        _lib.check(L.mfs_event_create(C.byref(e)))
-
-    def one_pass(i=None):
-        if i is not None:
-            _lib.check(L.mfs_event_record(ev[2 * i], stream))
-        _lib.check(L.mfs_plan_nd_run(plan, d_m0.ptr, 0, d_mean0.ptr, d_scale0.ptr, d_ys.ptr,
-                                     d_mom.ptr if d_mom else None, d_means.ptr, d_scales.ptr, d_nell.ptr, d_fn.ptr,
-                                     stream))
-        if i is not None:
-            _lib.check(L.mfs_event_record(ev[2 * i + 1], stream))
-        comm.allgather_nell(d_nell, d_nell_all, B, stream)
-
-    for _ in range(args.warmup):
-        one_pass()
-    _lib.check(L.mfs_stream_synchronize(stream))
-    comm.barrier()
-    _lib.check(L.mfs_device_synchronize())
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_pass(i)
-    _lib.check(L.mfs_stream_synchronize(stream))
-    _lib.check(L.mfs_device_synchronize())
-    comm.barrier()
-    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
-    kern_ms = []
-    for i in range(args.steps):
-        ms = C.c_float()
-        _lib.check(L.mfs_event_elapsed_ms(ev[2 * i], ev[2 * i + 1], C.byref(ms)))
-        kern_ms.append(ms.value)
-    kern_ms_avg = float(np.mean(kern_ms)) if kern_ms else float('nan')
-    first_nan = d_fn.to_array((B,), np.int32)
-    nell = d_nell.to_array((B,))
-    live_steps = int(np.where(first_nan >= 0, first_nan + 1, T).sum())
-    live_total = comm.sum_over_ranks(live_steps)
-    alive_total = comm.sum_over_ranks(int((first_nan < 0).sum()))
-    nell_all = d_nell_all.to_array((world * B,))
-    gather_ok = bool(np.array_equal(nell_all[rank * B:(rank + 1) * B], nell, equal_nan=True))
-    if rank == 0:
-        nominal_steps = world * B * T
-        value = live_total * args.steps / elapsed
-        per_step = 8 * (z + (3 if mode == 'central' else 5 if mode == 'scaled' else 1)) if d_mom else 8 * 2
-        algo_bytes = live_steps * per_step + B * 8 * (z + 3)
-        hbm_gbs = algo_bytes / (kern_ms_avg * 1e-3) / 1e9
-        flops_step = 2.0e6 if N == 6 else None   # SURVEY section 8d figure for config 5
-        out = {
-            'metric': 'filter time-steps/sec', 'value': value, 'unit': 'filter-steps/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'model': None, 'd': 2, 'N': N, 'z': int(z), 'T': T,
-                       'replicates_per_gpu': B, 'mode': mode, 'transition': transition,
-                       'parallelism': f'replicate-sharded x{world}', 'threads_per_filter': geo[0].value,
-                       'grid': geo[1].value, 'lds_bytes_per_block': geo[2].value,
-                       'moments_streamed_out': d_mom is not None},
-            'nominal_value': nominal_steps * args.steps / elapsed, 'live_fraction': live_total / nominal_steps,
-            'replicates_alive_at_T': alive_total, 'replicates': world * B, 'nll_allgather_ok': gather_ok,
-            'nll_allgather': ('rccl ncclAllGather' if comm.data == 'rccl' and world > 1 else
-                              'single rank: device copy' if world == 1 else f'host fallback: {comm.rccl_error}'),
-            'roofline': {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': hbm_gbs / HBM_PEAK_GBS,
-                         'traffic': recorded_hbm_traffic(args.workload, d_mom is not None)
-                         if (B == WORKLOADS[args.workload][3] and T == WORKLOADS[args.workload][2]) else None,
-                         'kernel': 'mfs::filternd_kernel',
-                         'avg_launch_ms': kern_ms_avg, 'algorithmic_bytes_per_launch': algo_bytes,
-                         'traffic_source': 'profiles/*/pmc.json (rocprofv3 --pmc, separate passes; the write counter includes '
-                                           'the kernel\'s scratch reload, see DESIGN.md section 3.3)',
-                         'note': 'latency-bound small-matrix recursion (Jacobi rounds), not HBM-bound'},
-        }
-        if flops_step:
-            tf = live_steps * flops_step / (kern_ms_avg * 1e-3) / 1e12
-            out['valu_fp64'] = {'achieved': tf, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                'frac': tf / FP64_VALU_PEAK_TFLOPS, 'algorithmic_flops_per_filter_step': flops_step}
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline_nd(args, N, T, mode, transition, mi, inds, ys, nell)
-        print(json.dumps(out))
-    _lib.check(L.mfs_plan_nd_destroy(plan))
+        w.release()
+    if world > 1 and not gather_ok and not args.allow_host_gather:
+        exit_code = dist.EXIT_RCCL_FAILED
     comm.close()
+    sys.exit(exit_code)
 
 
-def cpu_baseline_nd(args, N, T, mode, transition, mi, inds, ys, dev_nell):
+def end_to_end(w):
+    """Wall time of the reference-shaped Python entry point on the same workload: trace the callables, stage the host
+    arrays through the library's pool, run, copy every output back (PCIe-inclusive; never `value`)."""
+    from mfs_amd import _lib
+    t0 = time.perf_counter()
+    out = w.host_api_call()
+    first = time.perf_counter() - t0
+    del out
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out = w.host_api_call()
+        times.append(time.perf_counter() - t0)
+        del out
+    ms = float(np.median(times)) * 1e3
+    stats = _lib.pool_stats(w.device)
+    _lib.check(_lib.lib().mfs_pool_trim(w.device))
+    return {'end_to_end_ms': ms, 'end_to_end': {
+        'api': 'mfs_amd.*.filtering.moment_filter_* (host arrays in, pinned NumPy arrays out)', 'median_of': 3,
+        'first_call_ms': first * 1e3, 'all_ms': [t * 1e3 for t in times],
+        'nominal_steps_per_s': w.B * w.T / (ms * 1e-3),
+        'output_bytes': int(w.B * w.T * (w.z + 1) * 8), 'pool': stats}}
+
+
+def other_workloads(comm, device):
+    """Short runs (1 warm-up + 2 timed passes) of the other BASELINE configurations, kernel time from HIP events."""
+    out = {}
+    for name, B, label in OTHER_WORKLOADS:
+        try:
+            w = make_workload(name, B, 0, 0, device, fast_data=True)
+            res = timed_passes(w, comm, 2, 1, True, 0)
+            s = summarise(w, res, 2, 1, True)
+            out[label] = {'workload': name, 'replicates': w.B, 'T': w.T, 'N': w.N, 'kernel_ms': s['kernel_ms'],
+                          'ms_per_step': s['ms_per_step'], 'value': s['value'], 'nominal_value': s['nominal_value'],
+                          'live_fraction': s['live_fraction'], 'unit': 'filter-steps/s', 'kernel': w.kernel,
+                          'hbm_gbs_algorithmic': s['hbm_gbs']}
+            w.release()
+        except Exception as e:   # noqa: BLE001
+            out[label] = {'workload': name, 'error': repr(e)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1): the oracle on the host cores, as the checker and as a reported baseline
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_nd(args, w, res):
     """The NumPy/LAPACK oracle (one core) on one replicate over a bounded number of steps; kind = "port"."""
-    from oracle import multi_dims as omd, tme_sympy
+    from oracle import multi_dims as omd, tme_sympy, parity
+    mi, inds, T = w.mi, w.inds, w.T
     dt, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
-    kind, order = transition.rsplit('_', 1)
+    kind, order = w.transition.rsplit('_', 1)
     if kind == 'tme':
         _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, int(order), mi)
         sig = 'multi-index'
@@ -367,45 +556,36 @@ def cpu_baseline_nd(args, N, T, mode, transition, mi, inds, ys, dev_nell):
         sig = 'index'
     steps = 4
     t0 = time.perf_counter()
-    omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0, :steps], (mi, inds), ogs.cms, ogs.mean)
+    omd.moment_filter_nd_cms((ocms, sig), omean, opmf, w.ys[0, :steps], (mi, inds), ogs.cms, ogs.mean)
     el = time.perf_counter() - t0
     steps2 = int(min(T, max(steps, steps / el * args.cpu_seconds)))
     t0 = time.perf_counter()
-    res = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0, :steps2], (mi, inds), ogs.cms, ogs.mean)
+    ref = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, w.ys[0, :steps2], (mi, inds), ogs.cms, ogs.mean)
     el = time.perf_counter() - t0
     out = {'value': steps2 / el, 'unit': 'filter-steps/s', 'cores': 1, 'kind': 'port',
            'sample': f'replicate 0, first {steps2} of T={T} steps of the same workload, oracle/multi_dims.py '
                      f'(NumPy + LAPACK, lambdified SymPy transition), {el:.1f} s'}
+    if w.d_mom is not None and w.mode == 'central':
+        dev_m = w.d_mom.to_array((w.B, T, w.z))[0, :steps2]
+        dev_mean = w.d_means.to_array((w.B, T, 2))[0, :steps2]
+        out['max_rel_err_vs_device'] = {
+            'steps_compared': steps2,
+            'means': parity.quantity_errors(dev_mean, ref[1]),
+            'moments_all_orders_scaled': parity.quantity_errors(dev_m, ref[0], parity.moment_floor(ref[0])),
+            'moments_by_multi_index_max': parity.moment_errors_by_order(dev_m[None], ref[0][None])}
     if steps2 == T:
-        out['nll_rel_diff_vs_device'] = float(abs(res[2] - dev_nell[0]) / abs(res[2]))
+        out['nll_rel_diff_vs_device'] = float(abs(ref[2] - res['nell'][0]) / abs(ref[2]))
     return out
 
 
-def recorded_hbm_traffic(workload, moments_streamed):
-    """HBM bytes per launch from the committed PMC summary of this workload (counters cannot be read from inside the
-    process; they are collected with rocprofv3 --pmc in separate passes and committed under profiles/)."""
-    import glob
-    best = None
-    import re
-
-    def natural(path):   # r01_v9 before r01_v10
-        return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', path)]
-
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'pmc.json')), key=natural):
-        try:
-            with open(path) as f:
-                rec = json.load(f)
-        except (OSError, ValueError):
-            continue
-        if rec.get('workload') == workload and moments_streamed and 'hbm_bytes_per_launch' in rec:
-            best = rec['hbm_bytes_per_launch']
-    return best
-
-
-def cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, dev_nell, dev_first_nan):
+def cpu_baseline(args, w, res):
     """The oracle's C port (OpenMP over replicates) timed on this box's host cores, on a bounded sample of the same
-    workload.  The reference's own JAX-CPU path cannot run here (no JAX in the image): kind = "port"."""
-    from oracle import c_oracle, tme_sympy, models as om
+    workload, WITH moments: BASELINE.json's metric is "steps/s + max |moment err|", so the same sample yields the
+    per-quantity maximum relative error and the first-NaN agreement between the device and the CPU implementation.
+    The reference's own JAX-CPU path cannot run here (no JAX in the image): kind = "port"."""
+    from oracle import c_oracle, tme_sympy, models as om, parity
+    model, N, T, mode, tables, lik, ic, ys = w.model, w.N, w.T, w.mode, w.tables, w.lik, w.ic, w.ys
+    dev_nell, dev_first = res['nell'], np.where(res['first_nan'] >= 0, res['first_nan'], T)
     # all host cores this process may run on, regardless of OMP_NUM_THREADS (torchrun exports OMP_NUM_THREADS=1)
     try:
         threads = len(os.sched_getaffinity(0))
@@ -425,37 +605,52 @@ def cpu_baseline(args, model, N, T, mode, tables, lik, ic, ys, theta, dev_nell, 
     m0 = {'raw': ic.rms, 'central': ic.cms, 'scaled': ic.scms}[mode]
     modei = {'raw': 0, 'central': 1, 'scaled': 2}[mode]
 
-    def run(nb):
+    def run(nb, want_moments):
         cf = coef[:nb] if coef.ndim == 3 else coef
         lp = lik.params[:nb] if lik.params.ndim == 2 else lik.params
         t0 = time.perf_counter()
-        res = c_oracle.filter_1d(modei, N, ys[:nb], m0, ic.mean, np.sqrt(ic.variance), kind, umap, tables.n_terms,
-                                 cf, tables.mean_x_coef, lik_kind, lp, want_moments=False, nthreads=threads)
-        return time.perf_counter() - t0, res
+        r = c_oracle.filter_1d(modei, N, ys[:nb], m0, ic.mean, np.sqrt(ic.variance), kind, umap, tables.n_terms,
+                               cf, tables.mean_x_coef, lik_kind, lp, want_moments=want_moments, nthreads=threads)
+        return time.perf_counter() - t0, r
 
     nb = min(ys.shape[0], 4 * threads)
-    el, res = run(nb)
+    el, r = run(nb, False)
     rate = nb * T / el
-    nb2 = int(min(ys.shape[0], max(nb, rate * args.cpu_seconds / T)))
-    if nb2 > nb:
-        el, res = run(nb2)
-        nb = nb2
-    means = res[1]
-    first = np.where(np.isnan(means).any(1), np.argmax(np.isnan(means), 1), T)
-    live = int(first.sum())
-    both = np.isfinite(res[3]) & np.isfinite(dev_nell[:nb])
-    rel = np.abs(res[3][both] - dev_nell[:nb][both]) / np.abs(res[3][both]) if both.any() else np.array([np.nan])
-    return {'value': live / el, 'unit': 'filter-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'first {nb} replicates x T={T} of the same workload, oracle/c/mfs_oracle.c, OpenMP x{threads}, '
-                      f'{el:.1f} s; live steps only ({live / (nb * T):.2f} of nominal)',
-            'nominal_value': nb * T / el,
-            'nll_max_rel_diff_vs_device': float(np.max(rel)),
-            # the maximum is set by the one or two replicates closest to losing positive definiteness (any change of
-            # summation order moves them); the bulk shows the agreement of two fp64 implementations of the same algorithm
-            'nll_rel_diff_vs_device_p50_p90_p99': [float(v) for v in np.quantile(rel, [0.5, 0.9, 0.99])],
-            'replicates_finite_in_both': int(both.sum()),
-            'replicates_finite_device_only': int((np.isfinite(dev_nell[:nb]) & ~np.isfinite(res[3])).sum()),
-            'replicates_finite_cpu_only': int((~np.isfinite(dev_nell[:nb]) & np.isfinite(res[3])).sum())}
+    nb = int(min(ys.shape[0], max(nb, rate * args.cpu_seconds / T)))
+    nb = min(nb, max(1, int(3e9 // (T * 2 * N * 8))))     # host-memory bound of the moment sample
+    el, r = run(nb, True)
+    cm, cmeans, cscales, cnell = r
+    c_first = parity.first_nan_steps(np.concatenate([cmeans[..., None], cm], axis=-1), T) if mode != 'raw' \
+        else parity.first_nan_steps(cm, T)
+    live = int(np.minimum(c_first + 1, T).sum())
+    both = np.isfinite(cnell) & np.isfinite(dev_nell[:nb])
+    out = {'value': live / el, 'unit': 'filter-steps/s', 'cores': threads, 'kind': 'port',
+           'sample': f'first {nb} replicates x T={T} of the same workload incl. all 2N moments, oracle/c/mfs_oracle.c, '
+                     f'OpenMP x{threads}, {el:.1f} s; live steps only ({live / (nb * T):.2f} of nominal)',
+           'nominal_value': nb * T / el,
+           'replicates_finite_in_both': int(both.sum()),
+           'replicates_finite_device_only': int((np.isfinite(dev_nell[:nb]) & ~np.isfinite(cnell)).sum()),
+           'replicates_finite_cpu_only': int((~np.isfinite(dev_nell[:nb]) & np.isfinite(cnell)).sum()),
+           'first_nan_agreement_device_vs_cpu': parity.first_nan_agreement(dev_first[:nb], c_first, T)}
+    # ---- BASELINE.json: "max |moment err|" -- per quantity, over every filter-step finite on both sides
+    err = {'definition': 'relative error |device - cpu| / max(|cpu|, floor) over the filter-steps finite in both; moments '
+                         'scaled per order as in oracle/parity.py; the maxima are set by the replicates closest to losing '
+                         'positive definiteness (cond(Hankel) up to 1e16 at N = 15), the quantiles show the bulk',
+           'nll': parity.quantity_errors(dev_nell[:nb], cnell)}
+    if w.d_mom is not None:
+        dm = w.d_mom.to_array((w.B, T, 2 * N))[:nb]
+        floor = parity.moment_floor(cm)
+        err['moments_all_orders'] = parity.quantity_errors(dm, cm, floor)
+        err['moments_by_order_max'] = parity.moment_errors_by_order(dm, cm)
+        if mode == 'central':
+            err['variance'] = parity.quantity_errors(dm[..., 2], cm[..., 2])
+        del dm
+    if mode != 'raw':
+        err['mean'] = parity.quantity_errors(w.d_means.to_array((w.B, T))[:nb], cmeans, 1e-12)
+    if mode == 'scaled' and w.d_scales is not None:
+        err['scale'] = parity.quantity_errors(w.d_scales.to_array((w.B, T))[:nb], cscales)
+    out['max_rel_err_vs_device'] = err
+    return out
 
 
 if __name__ == '__main__':
