@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MFS_ABI_VERSION 1
+#define MFS_ABI_VERSION 2   /* 2: mfs_model_nd carries likelihood factors, ny and per-replicate tables; staging pool */
 
 /* return codes */
 #define MFS_OK 0
@@ -219,32 +219,41 @@ int mfs_elementary(int which, int n, const double* x, double* out, int device);
  * X' | x ~ N(mu(x), S(x)); rows 0..4 of coef hold the polynomials mu_0, mu_1, S_00, S_01, S_11 (n_terms = 5), the
  * other rows are ignored.  The kernel evaluates E[(X'_0-c_0)^a (X'_1-c_1)^b] by the Stein recursion, which is the
  * same polynomial in (mu - c, S) as Kan's sum.
- * The likelihood looks at one state component (mfs/multi_dims/ss_models.py:63-67).
+ * The likelihood is a product of up to MFS_ND_MAX_FACTORS factors, each a function of ONE state component and one
+ * column of the measurement: p(y | x) = prod_f lik(kind_f, params_f, y[ycol_f], x[component_f]).  One factor on x_0 is the
+ * prey--predator model (mfs/multi_dims/ss_models.py:63-67); two Gaussian factors, one per component, are the reference's
+ * measurement_cond_pdf_2d (tests/test_filtering.py:36-46: ys_2d of shape (T, 2), prod(norm.pdf(y, x, sd))).
  *
  *   N              quadrature order per dimension: s = N(N+1)/2 Gram size, z = N(2N+1) moments (|n| <= 2N-1), 2..7
  *   multi_indices  [z][2] int32, must equal the graded-lex table (checked: MFS_EINVAL otherwise, mirroring the
  *                  reference's only raise, multi_dims/filtering.py:238-239)
  *   inds           [3][s][s] int32 Gram / Hankel gather tables (gram_and_hankel_indices_graded_lexico)
- *   m0 [z] or [B][z]; mean0 [2] or [B][2] (central, scaled); scale0 likewise (scaled); ys [B][T]
+ *   m0 [z] or [B][z]; mean0 [2] or [B][2] (central, scaled); scale0 likewise (scaled); ys [B][T][ny]
  *   out_moments [B][T][z]; out_means [B][T][2] (central, scaled; NULL in raw mode); out_scales [B][T][2] (scaled);
  *   out_nell [B]; out_first_nan [B]
  */
 #define MFS_ND_TERMS 14
 #define MFS_ND_ROWS 16 /* coefficient blocks passed: MFS_ND_TERMS operator terms + 2 variance rows */
 #define MFS_ND_MAX_EXTENT 6
+#define MFS_ND_MAX_FACTORS 2
 #define MFS_ND_TRANS_OPERATOR 0
 #define MFS_ND_TRANS_GAUSSIAN 1
 typedef struct mfs_model_nd {
-    int32_t d;             /* 2 */
+    int32_t d;             /* 2 (d = 1 problems go through the 1-D entry points, which the reference guarantees equal:
+                              tests/test_filtering.py:304-329; mfs_amd.multi_dims.filtering routes them) */
     int32_t trans_kind;    /* MFS_ND_TRANS_* */
     int32_t n_terms;       /* MFS_ND_ROWS blocks are always passed; operator terms >= n_terms are known to be zero */
     int32_t extent;        /* D <= MFS_ND_MAX_EXTENT */
-    int32_t lik_kind;      /* MFS_LIK_* */
-    int32_t n_lik;
-    int32_t lik_component; /* which state component the likelihood reads */
-    int32_t reserved;      /* 0 */
-    const double* coef;    /* [MFS_ND_ROWS][D][D] */
-    const double* lik;     /* [n_lik] */
+    int32_t n_factors;     /* 1 .. MFS_ND_MAX_FACTORS likelihood factors */
+    int32_t ny;            /* measurement columns per step (1 or 2) */
+    int32_t fac_kind[MFS_ND_MAX_FACTORS];      /* MFS_LIK_* */
+    int32_t fac_component[MFS_ND_MAX_FACTORS]; /* state component the factor reads */
+    int32_t fac_ycol[MFS_ND_MAX_FACTORS];      /* measurement column the factor reads (< ny) */
+    int32_t fac_n_par[MFS_ND_MAX_FACTORS];     /* parameters used (<= MFS_MAX_LIK) */
+    int32_t coef_batched;  /* 0: one table; 1: one per replicate (per-replicate drift / dispersion parameters) */
+    int32_t lik_batched;   /* likewise for the likelihood parameters */
+    const double* coef;    /* [MFS_ND_ROWS][D][D] or [B][MFS_ND_ROWS][D][D] */
+    const double* lik;     /* [n_factors][MFS_MAX_LIK] or [B][n_factors][MFS_MAX_LIK], unused entries 0 */
 } mfs_model_nd;
 
 int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, int B, int z, const int32_t* multi_indices,

@@ -29,14 +29,18 @@ class MfsModel1d(C.Structure):
 class MfsModelNd(C.Structure):
     """struct mfs_model_nd (include/mfs_hip.h)."""
     _fields_ = [('d', C.c_int32), ('trans_kind', C.c_int32), ('n_terms', C.c_int32), ('extent', C.c_int32),
-                ('lik_kind', C.c_int32), ('n_lik', C.c_int32), ('lik_component', C.c_int32), ('reserved', C.c_int32),
-                ('coef', c_double_p), ('lik', c_double_p)]
+                ('n_factors', C.c_int32), ('ny', C.c_int32), ('fac_kind', C.c_int32 * 2),
+                ('fac_component', C.c_int32 * 2), ('fac_ycol', C.c_int32 * 2), ('fac_n_par', C.c_int32 * 2),
+                ('coef_batched', C.c_int32), ('lik_batched', C.c_int32), ('coef', c_double_p), ('lik', c_double_p)]
 
 
 ND_TERMS = 14
 ND_ROWS = 16
 ND_TRANS_OPERATOR, ND_TRANS_GAUSSIAN = 0, 1
 ND_MAX_EXTENT = 6
+ND_MAX_FACTORS = 2
+MAX_LIK = 4
+ABI_VERSION = 2
 # derivative multi-indices kappa, 1 <= |kappa| <= 4, graded-lex (the order of mfs_model_nd.coef rows)
 ND_KAPPAS = [(a, s - a) for s in range(1, 5) for a in range(s + 1)]
 

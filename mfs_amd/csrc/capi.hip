@@ -606,15 +606,23 @@ int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------
-// N-D filter (d = 2), host pointers
+// N-D filter (d = 2)
 // ---------------------------------------------------------------------------------------------------------------
 struct mfs_plan_nd {
-    int mode, N, T, B, stable, device, trans_kind;
+    int mode, N, T, B, stable, device, trans_kind, ny;
     mfs::FilterNdArgs args;   // model part filled at create (device pointers), data pointers per run
     double* d_coef = nullptr;
     double* d_lik = nullptr;
     int32_t* d_inds = nullptr;
 };
+
+static void destroy_plan_nd(mfs_plan_nd* p, bool quiesced) {
+    hipSetDevice(p->device);
+    if (!quiesced) hipDeviceSynchronize();   // pool blocks must be idle when they go back (what hipFree did implicitly)
+    mfs::BlockPool<false>& pool = mfs::device_state(p->device).device;
+    pool.release(p->d_coef); pool.release(p->d_lik); pool.release(p->d_inds);
+    delete p;
+}
 
 extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model, int mode, int N, int T, int B, int z,
                                   const int32_t* multi_indices, const int32_t* inds, int stable, int device) {
@@ -635,9 +643,14 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
     if (z != ke.Z) return fail(MFS_EINVAL, "The size of multi_indices %d must match that of the moments %d.", z, ke.Z);
     if (model->extent < 1 || model->extent > MFS_ND_MAX_EXTENT)
         return fail(MFS_EUNSUPPORTED, "coefficient extent %d outside [1, %d]", model->extent, MFS_ND_MAX_EXTENT);
-    if (model->lik_kind < 0 || model->lik_kind > MFS_LIK_GAUSSIAN || model->n_lik < 1 || model->n_lik > MFS_MAX_LIK ||
-        model->lik_component < 0 || model->lik_component > 1)
-        return fail(MFS_EINVAL, "bad likelihood description");
+    if (model->n_factors < 1 || model->n_factors > MFS_ND_MAX_FACTORS)
+        return fail(MFS_EINVAL, "n_factors %d outside [1, %d]", model->n_factors, MFS_ND_MAX_FACTORS);
+    if (model->ny < 1 || model->ny > 2) return fail(MFS_EINVAL, "ny %d outside [1, 2]", model->ny);
+    for (int f = 0; f < model->n_factors; ++f)
+        if (model->fac_kind[f] < 0 || model->fac_kind[f] > MFS_LIK_GAUSSIAN || model->fac_n_par[f] < 1 ||
+            model->fac_n_par[f] > MFS_MAX_LIK || model->fac_component[f] < 0 || model->fac_component[f] > 1 ||
+            model->fac_ycol[f] < 0 || model->fac_ycol[f] >= model->ny)
+            return fail(MFS_EINVAL, "bad description of likelihood factor %d", f);
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (!multi_indices || !inds || !model->coef || !model->lik) return fail(MFS_EINVAL, "NULL buffer");
     // the kernel derives a moment's multi-index from its position: insist on the graded-lex table
@@ -649,29 +662,40 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
     mfs_plan_nd* p = new (std::nothrow) mfs_plan_nd();
     if (!p) return fail(MFS_ENOMEM, "out of host memory");
     p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device;
-    p->trans_kind = model->trans_kind;
+    p->trans_kind = model->trans_kind; p->ny = model->ny;
     const size_t S = ke.S, DD = (size_t)model->extent * model->extent;
-    hipError_t e = hipMalloc((void**)&p->d_coef, MFS_ND_ROWS * DD * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_lik, MFS_MAX_LIK * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&p->d_inds, 3 * S * S * 4);
-    if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, MFS_ND_ROWS * DD * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, model->n_lik * 8, hipMemcpyHostToDevice);
+    const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * MFS_ND_ROWS * DD;
+    const size_t nlik = (size_t)(model->lik_batched ? B : 1) * model->n_factors * MFS_MAX_LIK;
+    mfs::BlockPool<false>& pool = mfs::device_state(device).device;
+    hipError_t e = pool.acquire((void**)&p->d_coef, ncoef * 8);
+    if (e == hipSuccess) e = pool.acquire((void**)&p->d_lik, nlik * 8);
+    if (e == hipSuccess) e = pool.acquire((void**)&p->d_inds, 3 * S * S * 4);
+    if (e == hipSuccess && ncoef) e = hipMemcpy(p->d_coef, model->coef, ncoef * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nlik) e = hipMemcpy(p->d_lik, model->lik, nlik * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_inds, inds, 3 * S * S * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->d_inds);
-        delete p;
+        destroy_plan_nd(p, true);
         return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_plan_nd_create: %s", hipGetErrorString(e));
     }
     mfs::FilterNdArgs& a = p->args;
     memset(&a, 0, sizeof(a));
     a.mode = mode; a.T = T; a.B = B; a.stable = stable;
     a.n_terms_used = model->n_terms; a.D = model->extent;
-    a.lik_kind = model->lik_kind; a.n_lik = model->n_lik; a.lik_component = model->lik_component;
-    for (int k = 0; k < MFS_ND_ROWS; ++k) {  // true extents of each coefficient block (trailing zero rows / columns cut)
+    a.n_factors = model->n_factors; a.ny = model->ny;
+    for (int f = 0; f < model->n_factors; ++f) {
+        a.fac_kind[f] = model->fac_kind[f]; a.fac_comp[f] = model->fac_component[f]; a.fac_ycol[f] = model->fac_ycol[f];
+    }
+    a.coef_batched = model->coef_batched; a.lik_batched = model->lik_batched;
+    // true extents of each coefficient block (trailing zero rows / columns cut); the union over replicates when batched
+    const size_t ntab = model->coef_batched ? (size_t)B : 1;
+    for (int k = 0; k < MFS_ND_ROWS; ++k) {
         int ea = 0, eb = 0;
-        for (int i = 0; i < model->extent; ++i)
-            for (int j = 0; j < model->extent; ++j)
-                if (model->coef[(size_t)k * DD + i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
+        for (size_t r = 0; r < ntab; ++r) {
+            const double* blk = model->coef + (r * MFS_ND_ROWS + k) * DD;
+            for (int i = 0; i < model->extent; ++i)
+                for (int j = 0; j < model->extent; ++j)
+                    if (blk[i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
+        }
         a.ext[k] = (ea == 0) ? 0 : (ea | (eb << 8));
     }
     a.coef = p->d_coef; a.lik = p->d_lik; a.inds = p->d_inds;
@@ -701,10 +725,7 @@ extern "C" int mfs_plan_nd_run(mfs_plan_nd* p, const double* d_m0, int m0_batche
 }
 
 extern "C" int mfs_plan_nd_destroy(mfs_plan_nd* p) {
-    if (!p) return MFS_OK;
-    hipSetDevice(p->device);
-    hipFree(p->d_coef); hipFree(p->d_lik); hipFree(p->d_inds);
-    delete p;
+    if (p) destroy_plan_nd(p, false);
     return MFS_OK;
 }
 
@@ -724,12 +745,12 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     mfs_plan_nd* plan = nullptr;
     int rc = mfs_plan_nd_create(&plan, model, mode, N, T, B, z, multi_indices, inds, stable, device);
     if (rc != MFS_OK) return rc;
-    struct Guard { mfs_plan_nd* p; ~Guard() { mfs_plan_nd_destroy(p); } } guard{plan};
+    struct Guard { mfs_plan_nd* p; ~Guard() { destroy_plan_nd(p, true); } } guard{plan};   // (every exit below is quiesced)
     if (!m0 || !out_nell || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "NULL buffer");
     if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
     if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
     if (B == 0) return MFS_OK;
-    const size_t Z = (size_t)z, nb = m0_batched ? B : 1;
+    const size_t Z = (size_t)z, nb = m0_batched ? B : 1, ny = (size_t)model->ny;
     double *d_m0 = nullptr, *d_mean0 = nullptr, *d_ys = nullptr, *d_mom = nullptr, *d_means = nullptr, *d_nell = nullptr,
            *d_scale0 = nullptr, *d_scales = nullptr;
     int32_t* d_fn = nullptr;
@@ -738,26 +759,26 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     hipError_t e = lease.context(&cx);
     if (e != hipSuccess) return fail(MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
     hipStream_t s = stream ? (hipStream_t)stream : cx->compute;
-    auto alloc = [&](void** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block(d, bytes); };
+    auto alloc = [&](auto** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block(d, bytes); };
     auto h2d = [&](void* d, const void* h, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
     };
     auto d2h = [&](void* h, const void* d, size_t bytes) {
         if (e == hipSuccess && h && d && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
     };
-    alloc((void**)&d_m0, nb * Z * 8);
-    alloc((void**)&d_mean0, nb * 2 * 8);
-    alloc((void**)&d_scale0, nb * 2 * 8);
-    alloc((void**)&d_ys, (size_t)B * T * 8);
-    if (out_moments) alloc((void**)&d_mom, (size_t)B * T * Z * 8);
-    if (out_means && mode != MFS_MODE_RAW) alloc((void**)&d_means, (size_t)B * T * 2 * 8);
-    if (out_scales && mode == MFS_MODE_SCALED) alloc((void**)&d_scales, (size_t)B * T * 2 * 8);
-    alloc((void**)&d_nell, (size_t)B * 8);
-    alloc((void**)&d_fn, (size_t)B * 4);
+    alloc(&d_m0, nb * Z * 8);
+    alloc(&d_mean0, nb * 2 * 8);
+    alloc(&d_scale0, nb * 2 * 8);
+    alloc(&d_ys, (size_t)B * T * ny * 8);
+    if (out_moments) alloc(&d_mom, (size_t)B * T * Z * 8);
+    if (out_means && mode != MFS_MODE_RAW) alloc(&d_means, (size_t)B * T * 2 * 8);
+    if (out_scales && mode == MFS_MODE_SCALED) alloc(&d_scales, (size_t)B * T * 2 * 8);
+    alloc(&d_nell, (size_t)B * 8);
+    alloc(&d_fn, (size_t)B * 4);
     h2d(d_m0, m0, nb * Z * 8);
     if (mean0) h2d(d_mean0, mean0, nb * 2 * 8);
     if (scale0 && mode == MFS_MODE_SCALED) h2d(d_scale0, scale0, nb * 2 * 8);
-    h2d(d_ys, ys, (size_t)B * T * 8);
+    h2d(d_ys, ys, (size_t)B * T * ny * 8);
     if (e == hipSuccess) {
         rc = mfs_plan_nd_run(plan, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn, s);
     }

@@ -3,19 +3,30 @@
 // Reference: mfs/multi_dims/filtering.py:210-344 (scan bodies :258-277, :326-341, :181-204),
 // mfs/multi_dims/quadratures.py:120-178 (moment_quadrature_nd), mfs/multi_dims/moments.py:414-479 (TME transition).
 //
-// One filter per 256-thread workgroup (4 waves); the k-loop runs inside the kernel.  Per half step:
-//   quadrature_nd  G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; Cholesky and both triangular
-//                  solves on one wave in registers (columns of L reach the other lanes as DPP operands after a lane-swap
-//                  duplication); K_k' = V_prev^T K_k V_prev warm start; both K_k diagonalised TOGETHER by cyclic Jacobi
-//                  (round-robin tournament from an LDS index table, one item = a 2x2 block of K_m + two eigenvector
-//                  row-pairs: 2 (s/2)^2 items <= 256 threads at s = 21) with the eigenvector matrices accumulated;
-//                  s^2 tensor-product nodes with weights <v0_i, v1_j> v0_i[0] v1_j[0]      (quadratures.py:165-170)
-//   predict        per node, sum_kappa Q_kappa(x) prod_k n_k!/(n_k-kappa_k)! (x_k-c_k)^(n_k-kappa_k) in its factorised
-//                  form (operator tables, moments.py:414-479) or the Stein recursion of a Normal closure (:257-411),
-//                  unrolled over the z moments so that every power / coefficient index is a compile-time constant
-//   update         likelihood-weighted raw / central / scaled-central moments
-// with the z moment sums formed 16 at a time through a transposing DPP row reduction into a [16 rows][z] LDS table.
-// No MFMA: s <= 28, fp64, sequential.
+// One filter per 256-thread workgroup (4 waves); the k-loop runs inside the kernel.
+//
+// The reference's rule has s^2 tensor-product nodes (lambda0_i, lambda1_j) with weights
+// W_ij = v0_i[0] <v0_i, v1_j> v1_j[0] (quadratures.py:165-170), so for a separable integrand
+//
+//     sum_ij W_ij f(x0_i) g(x1_j) = (f(X_0) e_0)^T (g(X_1) e_0),     X_k = scale_k K_k + mean_k I,        (*)
+//
+// the bilinear form of two matrix functions of K_k = R^-1 H_k R^-T applied to the first unit vector.  Every sum the
+// filter takes is a sum of such terms:
+//   predict (operator tables, moments.py:414-479)  the integrand sum_kappa Q_kappa(x) d^kappa (x - c)^n is a polynomial:
+//            (*) needs only the Krylov vectors K_k^p e_0 and NO eigen-decomposition; the moments are a contraction of
+//            the re-centred coefficient blocks with the array M[p][q] = (K_0^p e_0)^T (K_1^q e_0), binomially shifted
+//            to the new mean.  Same numbers as the node sums (1e-10 in an fp64 side-by-side over 150 steps), ~2 % of
+//            their flops, and the d eigensolves of quadratures.py:163 disappear from this half-step.
+//   update   the likelihood is a product of factors, each a function of ONE state component (ss_models.py:63-67,
+//            tests/test_filtering.py:44-46): h_k = lik_k(X_k) e_0 needs the eigen-decomposition of K_k for the
+//            components a factor reads ONLY (cyclic Jacobi, warm-started from the previous update rule); posterior
+//            moments are M[p][q] = (K_0^p h_0)^T (K_1^q h_1) / p_y shifted to the posterior mean.
+//   predict (Normal closures, moments.py:257-411)  E[(X' - c)^n | x] is a polynomial of degree ~ |n| deg(mu) in x:
+//            here the s^2 nodes are formed explicitly (both K_k diagonalised, weights as above) and the Stein recursion
+//            runs per node, 16 moments at a time through a transposing DPP row reduction.
+// Front end of every rule: G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; Cholesky and both
+// triangular solves on one wave in registers (columns of L reach the other lanes as DPP operands after a lane-swap
+// duplication).  No MFMA: s <= 28, fp64, sequential.
 #pragma once
 #include "filter1d_fast.hpp"
 
@@ -35,17 +46,19 @@ __device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / d
 struct FilterNdArgs {
     int mode, T, B, stable;
     int n_terms_used, D;      // coefficient block extent per variable (degree + 1)
-    int lik_kind, n_lik, lik_component;
+    int n_factors, ny;        // likelihood = prod_f lik(kind_f, params_f, y[ycol_f], x[comp_f]);  ys is [B][T][ny]
+    int fac_kind[2], fac_comp[2], fac_ycol[2];
+    int coef_batched, lik_batched;
     int ext[16];              // per-block true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
-    const double* coef;       // [kNdRows][D][D]: rows 0..13 Q_kappa in the fixed kappa order below (zeros where the
-                              // model has no term), rows 14, 15 the conditional variances of X'_0, X'_1 (scaled mode)
-    const double* lik;        // [n_lik]
+    const double* coef;       // [kNdRows][D][D] (or [B][...]): rows 0..13 Q_kappa in the fixed kappa order below (zeros
+                              // where the model has no term), rows 14, 15 the conditional variances of X'_0, X'_1 (scaled mode)
+    const double* lik;        // [n_factors][4] (or [B][n_factors][4])
     const int32_t* inds;      // [3][s][s]
     const double* m0;         // [z] or [B][z]
     int m0_batched;
     const double* mean0;      // [2] or [B][2]
     const double* scale0;     // [2] or [B][2] (scaled mode)
-    const double* ys;         // [B][T]
+    const double* ys;         // [B][T][ny]
     double* out_mom;          // [B][T][z]
     double* out_mean;         // [B][T][2]
     double* out_scale;        // [B][T][2] (scaled mode)
@@ -103,9 +116,17 @@ struct NdTile {
     static constexpr bool kTables = (2 * HP * HP <= 256) && (2 * S * HP <= 512);
     static constexpr int oIdxK = oMisc + 8;
     static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
-    static constexpr int oIdxV = oIdxK + nIdxK;
-    static constexpr int nIdxV = 0;
-    static constexpr int kDoubles = oIdxV + nIdxV;
+    // bilinear-form path: Krylov tiles, the moment array of the rule and its shifted copy, re-centred coefficients
+    static constexpr int NPW = P + kNdMaxD;                  // powers 0 .. 2N-1 + (D-1)
+    static constexpr int MLD = NPW + 1;
+    static constexpr int oPK = oIdxK + nIdxK;                // [2][NPW][NP]
+    static constexpr int oM = oPK + 2 * NPW * NP;            // [NPW][MLD]
+    static constexpr int oM2 = oM + NPW * MLD;               // [NPW][MLD]
+    static constexpr int oQs = oM2 + NPW * MLD;              // [kNdRows][kNdMaxD * kNdMaxD]
+    static constexpr int oBin = oQs + kNdRows * kNdMaxD * kNdMaxD;  // [NPW][NPW] binomial coefficients
+    static constexpr int oBx = oBin + NPW * NPW;             // [kNdMaxD][kNdMaxD] raw-monomial sums, then 8 scalars
+    static constexpr int oLik = oBx + kNdMaxD * kNdMaxD + 8; // [2][4] likelihood factor parameters
+    static constexpr int kDoubles = oLik + 8;
 };
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -184,32 +205,26 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
     else { p = r + P; if (p >= NP - 1) p -= NP - 1; q = r - P; if (q < 0) q += NP - 1; }
 }
 
-// Fills lam[2][NP] and W[S][S]; returns block-uniform poison flag.
+// Front end of a rule: gather, Cholesky (or LDL^T completion), both triangular solves, symmetrisation.  Leaves the
+// symmetric K_0, K_1 in their LDS tiles; returns the block-uniform poison flag (a pivot that is not > 0).
 template <int N>
-__device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable,
-                              const bool warm) {
+__device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
     using L = NdTile<N>;
-    constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
+    constexpr int S = L::S, NP = L::NP, LD = L::LD;
     const int tid = threadIdx.x, nthr = blockDim.x;
     double* mom = Sm + L::oMom;
     double* A = Sm + L::oA;
     double* K = Sm + L::oK;
-    double* V = Sm + L::oV;
-    double* cs = Sm + L::oCs;
     double* flags = Sm + L::oMisc + 4;
 
     ND_STAMP_BEGIN;
-    // -- gather (quadratures.py:151-152); pad rows / columns are zero, V = I
+    // -- gather (quadratures.py:151-152); pad rows / columns are zero
     for (int e = tid; e < NP * NP; e += nthr) {
         const int i = e / NP, j = e - i * NP;
         const bool in = (i < S) && (j < S);
         A[i * LD + j] = in ? mom[inds[i * S + j]] : 0.0;
         K[i * LD + j] = in ? mom[inds[S * S + i * S + j]] : 0.0;
         K[NP * LD + i * LD + j] = in ? mom[inds[2 * S * S + i * S + j]] : 0.0;
-        if (!warm) {
-            V[i * LD + j] = (i == j) ? 1.0 : 0.0;
-            V[NP * LD + i * LD + j] = (i == j) ? 1.0 : 0.0;
-        }
     }
     if (tid == 0) flags[0] = 0.0;
     __syncthreads();
@@ -346,15 +361,40 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     __syncthreads();
 
     ND_STAMP(2);
+    return flags[0] != 0.0;
+}
+
+// Cyclic Jacobi with eigenvectors (quadratures.py:163) on the matrices m in [mbeg, mend) -- both K_k for a Normal-closure
+// prediction, only the components a likelihood factor reads for an update.  warm_mask: bit m set = V_m holds the
+// eigenvectors of an earlier rule of this filter.  On return the diagonal of K_m holds the eigenvalues, V_m the vectors.
+template <int N>
+__device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int mend, const int warm_mask) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    double* A = Sm + L::oA;
+    double* K = Sm + L::oK;
+    double* V = Sm + L::oV;
+    double* cs = Sm + L::oCs;
+    double* flags = Sm + L::oMisc + 4;
+    const int nm = mend - mbeg;
+    bool warm = true;   // every matrix of the range warm-started
+    for (int m = mbeg; m < mend; ++m) warm = warm && ((warm_mask >> m) & 1);
+    ND_STAMP_BEGIN;
+    for (int e = tid; e < nm * NP * NP; e += nthr) {
+        const int m = mbeg + e / (NP * NP), f = e % (NP * NP), i = f / NP, j = f - i * NP;
+        if (!((warm_mask >> m) & 1)) V[m * NP * LD + i * LD + j] = (i == j) ? 1.0 : 0.0;
+    }
     // -- warm start: the eigenvector matrices of the previous rule are still in LDS.  K changes little between
     //    consecutive rules, so V_prev^T K V_prev is already nearly diagonal and the sweeps below converge
     //    quadratically from there (2-3 sweeps instead of 8-9); V then accumulates on top of V_prev.  The tile of the
     //    Cholesky factor is free by now and serves as the temporary.
-    if (warm) {
-        // both matrices in the same two stages (the weight tile, free until the end of the rule, is the second scratch)
+    if (warm_mask & (((1 << nm) - 1) << mbeg)) {
+        // all warm matrices of the range in the same two stages (the weight tile, free until the end of the rule, is the second scratch)
         double* A1 = Sm + L::oW;   // [S][S]
-        for (int e = tid; e < 2 * S * S; e += nthr) {   // A_m = K_m V_m
-            const int m = e / (S * S), f = e - m * S * S, i = f / S, j = f - i * S;
+        for (int e = tid; e < nm * S * S; e += nthr) {   // A_m = K_m V_m
+            const int m = mbeg + e / (S * S), f = e % (S * S), i = f / S, j = f - i * S;
+            if (!((warm_mask >> m) & 1)) continue;
             const double* Kk = K + m * NP * LD;
             const double* Vk = V + m * NP * LD;
             double acc = 0.0;
@@ -364,8 +404,9 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         }
         __syncthreads();
         constexpr int TRI = S * (S + 1) / 2;
-        for (int e = tid; e < 2 * TRI; e += nthr) {     // K_m = V_m^T A_m on the lower triangle, symmetrised on the fly
-            const int m = e / TRI, t = e - m * TRI;
+        for (int e = tid; e < nm * TRI; e += nthr) {     // K_m = V_m^T A_m on the lower triangle, symmetrised on the fly
+            const int m = mbeg + e / TRI, t = e % TRI;
+            if (!((warm_mask >> m) & 1)) continue;
             int i = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
             i += ((i + 1) * (i + 2) / 2 <= t) ? 1 : 0;
             i -= (i * (i + 1) / 2 > t) ? 1 : 0;
@@ -390,7 +431,7 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     ND_STAMP(3);
     // -- cyclic Jacobi on both matrices with eigenvectors (quadratures.py:163)
     double prev_off = 1.79e308;
-    const int kw_slot = (tid < 2 * HP * HP) ? tid % (HP * HP) : 0;
+    const int kw_slot = (tid < nm * HP * HP) ? tid % (HP * HP) : 0;
     unsigned kw_next = 0;
     if constexpr (L::kTables) kw_next = reinterpret_cast<const unsigned*>(Sm + L::oIdxK)[kw_slot];
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
@@ -400,8 +441,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
         // off / dia: off-diagonal and diagonal mass; xsq = sum_{i != j} (K_ij / (K_jj - K_ii))^2, the squared size of the
         // first-order eigenvector correction (below)
         double off = 0.0, dia = 0.0, xsq = 0.0;
-        for (int e = tid; e < 2 * S * S; e += nthr) {
-            const double* Kk = K + (e / (S * S)) * NP * LD;
+        for (int e = tid; e < nm * S * S; e += nthr) {
+            const double* Kk = K + (mbeg + e / (S * S)) * NP * LD;
             const int f = e % (S * S), i = f / S, j = f - i * S;
             const double v = Kk[i * LD + j];
             const double dd = Kk[j * (LD + 1)] - Kk[i * (LD + 1)];
@@ -434,15 +475,15 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             // I + X, X_ij = E_ij / (d_j - d_i) (antisymmetric, so I + X is orthogonal up to X^T X <= 1e-14), the
             // eigenvalues d_j + sum_i E_ij X_ij -- as accurate as one more sweep at the price of one S x S x S product
             // per matrix instead of S - 1 rounds of rotations (close eigenvalues make X large and take the sweep)
-            for (int e = tid; e < 2 * S * S; e += nthr) {      // X over the off-diagonal of K (the diagonal stays)
-                double* Kk = K + (e / (S * S)) * NP * LD;
+            for (int e = tid; e < nm * S * S; e += nthr) {      // X over the off-diagonal of K (the diagonal stays)
+                double* Kk = K + (mbeg + e / (S * S)) * NP * LD;
                 const int f = e % (S * S), i = f / S, j = f - i * S;
                 if (i != j) Kk[i * LD + j] = Kk[i * LD + j] / (Kk[j * (LD + 1)] - Kk[i * (LD + 1)]);
             }
             __syncthreads();
             double* T1 = Sm + L::oW;
-            for (int e = tid; e < 2 * S * S; e += nthr) {      // T_m = V_m X_m
-                const int m = e / (S * S), f = e - m * S * S, k = f / S, j = f - k * S;
+            for (int e = tid; e < nm * S * S; e += nthr) {      // T_m = V_m X_m
+                const int m = mbeg + e / (S * S), f = e % (S * S), k = f / S, j = f - k * S;
                 const double* Kk = K + m * NP * LD;
                 const double* Vk = V + m * NP * LD;
                 double acc = 0.0;
@@ -450,8 +491,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 for (int i = 0; i < S; ++i) acc = fma(Vk[k * LD + i], (i == j) ? 0.0 : Kk[i * LD + j], acc);
                 if (m == 0) A[k * LD + j] = acc; else T1[k * S + j] = acc;
             }
-            for (int e = tid; e < 2 * S; e += nthr) {          // second-order eigenvalues, parked in the rotation records
-                const int m = e / S, j = e - m * S;
+            for (int e = tid; e < nm * S; e += nthr) {          // second-order eigenvalues, parked in the rotation records
+                const int m = mbeg + e / S, j = e % S;
                 const double* Kk = K + m * NP * LD;
                 const double dj = Kk[j * (LD + 1)];
                 double acc = dj;
@@ -462,11 +503,11 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                 cs[e] = acc;
             }
             __syncthreads();
-            for (int e = tid; e < 2 * S * S; e += nthr) {
-                const int m = e / (S * S), f = e - m * S * S, k = f / S, j = f - k * S;
+            for (int e = tid; e < nm * S * S; e += nthr) {
+                const int m = mbeg + e / (S * S), f = e % (S * S), k = f / S, j = f - k * S;
                 V[m * NP * LD + k * LD + j] += (m == 0) ? A[k * LD + j] : T1[k * S + j];
             }
-            for (int e = tid; e < 2 * S; e += nthr) K[(e / S) * NP * LD + (e % S) * (LD + 1)] = cs[e];
+            for (int e = tid; e < nm * S; e += nthr) K[(mbeg + e / S) * NP * LD + (e % S) * (LD + 1)] = cs[e];
             break;
         }
         prev_off = off;
@@ -486,16 +527,16 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             // K and write their own records, so these loads are in flight while wave 0 works through the rotation chain
             double a11 = 0.0, a12 = 0.0, a21 = 0.0, a22 = 0.0, x0 = 0.0, x1 = 0.0, y0 = 0.0, y1 = 0.0;
             if constexpr (L::kTables) {
-                const int mB = (tid < 2 * HP * HP) ? tid / (HP * HP) : 0;
-                const int Q = ((tid < 2 * HP * HP) ? tid % (HP * HP) : 0) % HP;
+                const int mB = (tid < nm * HP * HP) ? mbeg + tid / (HP * HP) : mbeg;
+                const int Q = ((tid < nm * HP * HP) ? tid % (HP * HP) : 0) % HP;
                 const double* Kk = K + mB * NP * LD;
                 const double* Va = V + mB * NP * LD + Q * LD;
                 const double* Vb = V + mB * NP * LD + (Q + HP) * LD;
                 a11 = Kk[o11]; a12 = Kk[o12]; a21 = Kk[o21]; a22 = Kk[o22];
                 x0 = Va[p1]; x1 = Va[p2]; y0 = Vb[p1]; y1 = Vb[p2];
             }
-            if (tid < 2 * HP) {
-                const int m = tid / HP, P = tid - m * HP;
+            if (tid < nm * HP) {
+                const int m = mbeg + tid / HP, P = tid % HP;
                 double* Kk = K + m * NP * LD;
                 int p, q;
                 tournament_pair<NP>(r, P, p, q);
@@ -525,8 +566,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
             if constexpr (2 * HP * HP <= 256 && 2 * S * HP <= 512) {
                 // item (m, P, Q): the 2x2 block (pair P, pair Q) of K_m and the eigenvector entries of rows Q and Q + HP in
                 // the two columns of pair P -- both need the rotation of pair P, so an item reads two rotations, not four
-                const bool hasB = tid < 2 * HP * HP;
-                const int mB = hasB ? tid / (HP * HP) : 0, blk = hasB ? tid - mB * HP * HP : 0;
+                const bool hasB = tid < nm * HP * HP;
+                const int mB = hasB ? mbeg + tid / (HP * HP) : mbeg, blk = hasB ? tid % (HP * HP) : 0;
                 const int P = blk / HP, Q = blk - P * HP;
                 double* Kk = K + mB * NP * LD;
                 double* Va = V + mB * NP * LD + Q * LD;
@@ -553,8 +594,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                     Vb[p1] = cP * y0 - sP * y1; Vb[p2] = sP * y0 + cP * y1;
                 }
             } else {  // larger N: the same work in strided loops
-                for (int e = tid; e < 2 * HP * HP; e += nthr) {
-                    const int m = e / (HP * HP), blk = e - m * HP * HP, P = blk / HP, Q = blk - P * HP;
+                for (int e = tid; e < nm * HP * HP; e += nthr) {
+                    const int m = mbeg + e / (HP * HP), blk = e % (HP * HP), P = blk / HP, Q = blk - P * HP;
                     double* Kk = K + m * NP * LD;
                     const double* csm = cs + m * HP * 3;
                     int p1, p2, q1, q2;
@@ -576,8 +617,8 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
                     Kk[p1 * LD + q1] = b11; Kk[p1 * LD + q2] = b12;
                     Kk[p2 * LD + q1] = b21; Kk[p2 * LD + q2] = b22;
                 }
-                for (int e = tid; e < 2 * S * HP; e += nthr) {
-                    const int m = e / (S * HP), f = e - m * S * HP, row = f / HP, P = f - row * HP;
+                for (int e = tid; e < nm * S * HP; e += nthr) {
+                    const int m = mbeg + e / (S * HP), f = e % (S * HP), row = f / HP, P = f - row * HP;
                     double* Vk = V + m * NP * LD;
                     const double* csm = cs + m * HP * 3;
                     int p, q;
@@ -593,8 +634,17 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     }
     __syncthreads();
     ND_STAMP(4);
-    const bool poisoned = flags[0] != 0.0;
+}
 
+// Eigenvalues and tensor-product weights of the s^2-node rule (quadratures.py:165-170); Normal-closure predictions only.
+template <int N>
+__device__ void weights_nd(double* __restrict__ Sm) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, NP = L::NP, LD = L::LD;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const double* K = Sm + L::oK;
+    const double* V = Sm + L::oV;
+    ND_STAMP_BEGIN;
     // -- eigenvalues and tensor-product weights (quadratures.py:165-170)
     double* lam = Sm + L::oLam;
     double* W = Sm + L::oW;
@@ -609,23 +659,108 @@ __device__ bool quadrature_nd(double* __restrict__ Sm, const int32_t* __restrict
     }
     __syncthreads();
     ND_STAMP(5);
-    return poisoned;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bilinear-form path (identity (*) at the top of this file)
+// ---------------------------------------------------------------------------------------------------------------------
+// Krylov vectors PK[w][p] = K_w^p PK[w][0], p < npow, for the matrices in wmask at once: wave w owns K_w, lane i row i of
+// it in registers; a step is S broadcast LDS reads of the previous vector and S multiply-adds.  No block barrier inside (one
+// wave per chain; LDS executes a wave's accesses in order); the caller synchronises before and after.
+template <int N>
+__device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW;
+    const int tid = threadIdx.x;
+    if (tid < 128 && ((wmask >> (tid >> 6)) & 1)) {
+        const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
+        const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
+        double* pk = Sm + L::oPK + w * NPW * NP;
+        double kr[S];
+        static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
+        for (int p = 1; p < npow; ++p) {
+            wave_sync();
+            const double* u = pk + (p - 1) * NP;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            static_for<0, S>([&](auto Jc) {
+                constexpr int j = Jc;
+                if constexpr (j % 3 == 0) a0 = fma(kr[j], u[j], a0);
+                else if constexpr (j % 3 == 1) a1 = fma(kr[j], u[j], a1);
+                else a2 = fma(kr[j], u[j], a2);
+            });
+            if (lane < S) pk[p * NP + lane] = (a0 + a1) + a2;
+        }
+    }
+}
+
+// M[p][q] = sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow: the moments sum_ij W_ij f_p(xi0_i) g_q(xi1_j) of the rule
+// about its own centre (xi = x - mean = scale * lambda).
+template <int N>
+__device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const double sc0, const double sc1) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD;
+    const double* p0 = Sm + L::oPK;
+    const double* p1 = Sm + L::oPK + NPW * NP;
+    double* M = Sm + L::oM;
+    for (int e = threadIdx.x; e < npow * npow; e += blockDim.x) {
+        const int p = e / npow, q = e - p * npow;
+        const double* u = p0 + p * NP;
+        const double* v = p1 + q * NP;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j + 1 < S; j += 2) { a0 = fma(u[j], v[j], a0); a1 = fma(u[j + 1], v[j + 1], a1); }
+        if constexpr (S & 1) a0 = fma(u[S - 1], v[S - 1], a0);
+        double f = 1.0;
+        for (int k = 0; k < p; ++k) f *= sc0;
+        for (int k = 0; k < q; ++k) f *= sc1;
+        M[p * MLD + q] = (a0 + a1) * f;
+    }
+}
+
+// M2[a][b] = fac * sum_{j0 <= a, j1 <= b} C(a, j0) (-d0)^(a-j0) C(b, j1) (-d1)^(b-j1) M[j0][j1] for a, b < nout: the
+// same sums about the shifted centre (xi - d).  Two separable passes; M is overwritten by the intermediate.
+template <int N>
+__device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const double d0, const double d1, const double fac) {
+    using L = NdTile<N>;
+    constexpr int NPW = L::NPW, MLD = L::MLD;
+    double* M = Sm + L::oM;
+    double* M2 = Sm + L::oM2;
+    const double* bin = Sm + L::oBin;
+    for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q]
+        const int a = e / nout, q = e - a * nout;
+        double acc = 0.0, pw = 1.0;
+        for (int j = a; j >= 0; --j) { acc = fma(bin[a * NPW + j] * pw, M[j * MLD + q], acc); pw *= -d0; }
+        M2[a * MLD + q] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
+        const int a = e / nout, b = e - a * nout;
+        double acc = 0.0, pw = 1.0;
+        for (int j = b; j >= 0; --j) { acc = fma(bin[b * NPW + j] * pw, M2[a * MLD + j], acc); pw *= -d1; }
+        M[a * MLD + b] = acc * fac;
+    }
+    __syncthreads();
 }
 
 // TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
 template <int N, int TK>
 __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N>;
-    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, R = L::R, RW = L::RW, ZB = L::ZB;
+    constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
+    constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = kNdMaxD * kNdMaxD;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const bool scaled = a.mode == MFS_MODE_SCALED;
+    const bool raw = a.mode == MFS_MODE_RAW;
     double* mom = Sm + L::oMom;
     const double* coef = Sm + L::oCoef;
-    const double* lp = Sm + L::oMisc;
+    double* M = Sm + L::oM;
     const int DD = a.D * a.D;
 
-    for (int e = tid; e < kNdRows * DD; e += 256) Sm[L::oCoef + e] = a.coef[e];
+    {
+        const double* src = a.coef + (a.coef_batched ? (size_t)b * kNdRows * DD : 0);
+        for (int e = tid; e < kNdRows * DD; e += 256) Sm[L::oCoef + e] = src[e];
+    }
     if constexpr (L::kTables) {
         constexpr int HP = L::HP;
         unsigned* kt = reinterpret_cast<unsigned*>(Sm + L::oIdxK);
@@ -637,102 +772,184 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             kt[e] = (unsigned)p1 | ((unsigned)p2 << 8) | ((unsigned)q1 << 16) | ((unsigned)q2 << 24);
         }
     }
-    if (tid < 4) Sm[L::oMisc + tid] = (tid < a.n_lik) ? a.lik[tid] : 0.0;
+    for (int e = tid; e < NPW * NPW; e += 256) {   // binomial coefficients C(i, j), exact in fp64 for i < 2N + 6 <= 20
+        const int i = e / NPW, j = e - i * NPW;
+        double c = (j <= i) ? 1.0 : 0.0;
+        for (int k = 1; k <= j && j <= i; ++k) c = c * (double)(i - j + k) / (double)k;
+        Sm[L::oBin + e] = c;
+    }
+    if (tid < 8) {
+        const double* src = a.lik + (a.lik_batched ? (size_t)b * a.n_factors * 4 : 0);
+        Sm[L::oLik + tid] = (tid < a.n_factors * 4) ? src[tid] : 0.0;
+    }
     {
         const double* src = a.m0 + (a.m0_batched ? (size_t)b * Z : 0);
         for (int e = tid; e < Z; e += 256) mom[e] = src[e];
     }
-    // every thread carries an identical copy of the block-uniform state (mean, nell): they are all computed from the
-    // same LDS-reduced sums, so no broadcast is ever needed
+    // every thread carries an identical copy of the block-uniform state (mean, scale, nell): they are all computed from
+    // the same LDS values, so no broadcast is ever needed
     double mean0 = 0.0, mean1 = 0.0, nell = 0.0;
     double scale0 = 1.0, scale1 = 1.0;
-    if (a.mode != MFS_MODE_RAW) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
+    if (!raw) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
     if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
     double* red = Sm + L::oRed;
     if (tid == 0) { red[16 * ZB] = 0.0; Sm[L::oMisc + 5] = __hiloint2double(0, -1); }   // flag slot 1: step of the first non-finite result (an int in the low word)
+    // which matrices an update diagonalises: the components a likelihood factor reads
+    int lik_mask = 0;
+    for (int f = 0; f < a.n_factors; ++f) lik_mask |= 1 << a.fac_comp[f];
+    const int ubeg = (lik_mask & 1) ? 0 : 1, uend = (lik_mask & 2) ? 2 : 1;
     __syncthreads();
     bool dead = false;
-    bool warm = false;
+    int warm_mask = 0;
     const double qnan = __builtin_nan("");
-    const double* yrow = a.ys + (size_t)b * a.T;
+    const double* yrow = a.ys + (size_t)b * a.T * a.ny;
+    double* bx = Sm + L::oBx;
+    double* qs = Sm + L::oQs;
 
     for (int t = 0; t < a.T; ++t) {
-        const double y = yrow[t];
         if (!dead) {
             bool bad = false;
-#pragma nounroll
-            for (int half = 0; half < 2; ++half) {
-                // half 0 = prediction (filtering.py:262-266 / :330-331), half 1 = update (:268-275 / :333-339)
-                const bool poisoned = quadrature_nd<N>(Sm, a.inds, a.stable, warm);
-                warm = !poisoned;
-                ND_STAMP_BEGIN;
-                const double* lam = Sm + L::oLam;
-                const double* W = Sm + L::oW;
-                const double qm0 = mean0, qm1 = mean1;  // the centre this quadrature's nodes are built around
-                const double qs0 = scale0, qs1 = scale1; // and their scales (1 unless scaled mode)
-                // ---- pass 1: the scalar sums (conditional means, or p_y and the posterior mean)
-                double s0 = 0.0, s1 = 0.0, s4 = 0.0, s2 = 0.0, s3 = 0.0;
-                for (int e = tid; e < R; e += 256) {
-                    const int i0 = e / S, i1 = e - i0 * S;
-                    const double w = W[e];
-                    const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[NP + i1], qs1, qm1);
-                    if (half == 0) {
-                        if constexpr (TK == 0) {
-                            s0 = fma(w, x0 + poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s0);  // kappa = (1, 0): E[X'_0 | x]
-                            s1 = fma(w, x1 + poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s1);  // kappa = (0, 1)
-                        } else {
-                            s0 = fma(w, poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s0);       // mu_0(x)
-                            s1 = fma(w, poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s1);       // mu_1(x)
+            // =========================================================================================================
+            // prediction (filtering.py:262-266 / :330-331 / :183-190)
+            // =========================================================================================================
+            {
+                const bool poisoned = front_nd<N>(Sm, a.inds, a.stable);
+                bad = bad || poisoned;
+                double c0 = 0.0, c1 = 0.0, ns0 = 1.0, ns1 = 1.0;
+                if constexpr (TK == 0) {
+                    ND_STAMP_BEGIN;
+                    // ---- Krylov vectors from e_0 and the moment array of the rule about its own centre
+                    const int npow = P + a.D - 1;
+                    if (tid < 2 * NP) Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
+                    __syncthreads();
+                    krylov_nd<N>(Sm, npow, 3);
+                    __syncthreads();
+                    bilinear_moments_nd<N>(Sm, npow, scale0, scale1);
+                    __syncthreads();
+                    // ---- raw-monomial sums Bx[i][j] = sum W x0^i x1^j, x = xi + mean (the conditional means and
+                    //      variances are polynomials in x): binomial un-shift of the low corner of M
+                    if (tid < DD6) {
+                        const int i = tid / kNdMaxD, j = tid - i * kNdMaxD;
+                        double acc = 0.0;
+                        if (i < a.D && j < a.D) {
+                            const double* bin = Sm + L::oBin;
+                            double pi = 1.0;
+                            for (int al = i; al >= 0; --al) {
+                                double pj = 1.0, row = 0.0;
+                                for (int be = j; be >= 0; --be) { row = fma(bin[j * NPW + be] * pj, M[al * MLD + be], row); pj *= mean1; }
+                                acc = fma(bin[i * NPW + al] * pi, row, acc);
+                                pi *= mean0;
+                            }
                         }
-                        if (scaled) {  // scale <- sqrt(sum w var_k(x)), filtering.py:186
-                            constexpr int v0 = (TK == 0) ? 14 : 2, v1 = (TK == 0) ? 15 : 4;
-                            s2 = fma(w, poly2d(coef + v0 * DD, a.D, a.ext[v0], x0, x1), s2);
-                            s3 = fma(w, poly2d(coef + v1 * DD, a.D, a.ext[v1], x0, x1), s3);
-                        }
-                    } else {
-                        const double wl = w * likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? x0 : x1);
-                        s0 = fma(wl, x0, s0); s1 = fma(wl, x1, s1); s4 += wl;
+                        bx[tid] = acc;
                     }
-                }
-                s0 = wave_sum64(s0); s1 = wave_sum64(s1); s4 = wave_sum64(s4);
-                if (scaled && half == 0) { s2 = wave_sum64(s2); s3 = wave_sum64(s3); }
-                if ((tid & 63) == 0) {
-                    double* r3 = red + 4 * RW * (tid >> 6) + 16 * ZB;
-                    r3[1] = s0; r3[2] = s1; r3[3] = s4; r3[4] = s2; r3[5] = s3;
-                }
-                __syncthreads();
-                {
-                    const double* q = red + 16 * ZB;
-                    s0 = q[1] + q[4 * RW + 1] + q[8 * RW + 1] + q[12 * RW + 1];
-                    s1 = q[2] + q[4 * RW + 2] + q[8 * RW + 2] + q[12 * RW + 2];
-                    s4 = q[3] + q[4 * RW + 3] + q[8 * RW + 3] + q[12 * RW + 3];
-                    s2 = q[4] + q[4 * RW + 4] + q[8 * RW + 4] + q[12 * RW + 4];
-                    s3 = q[5] + q[4 * RW + 5] + q[8 * RW + 5] + q[12 * RW + 5];
-                }
-                double c0 = 0.0, c1 = 0.0, py = 1.0;
-                if (half == 0) {
-                    if (a.mode != MFS_MODE_RAW) { c0 = s0; c1 = s1; }
+                    __syncthreads();
+                    if (tid < 4) {   // 0, 1: E[X'_k] - x_k summed; 2, 3: conditional variances (scaled mode)
+                        const int row = (tid == 0) ? 1 : (tid == 1) ? 0 : 12 + tid;   // kappa (1,0) is row 1, (0,1) row 0
+                        const int ea = a.ext[row] & 0xff, eb = a.ext[row] >> 8;
+                        double acc = 0.0;
+                        for (int i = 0; i < ea; ++i)
+                            for (int j = 0; j < eb; ++j) acc = fma(coef[row * DD + i * a.D + j], bx[i * kNdMaxD + j], acc);
+                        bx[DD6 + tid] = acc;
+                    }
+                    __syncthreads();
+                    // E[X'_k | x] = x_k + Q_{e_k}(x): the mean of the prediction is the rule's own first moment plus the sum
+                    if (!raw) { c0 = mean0 + M[1 * MLD + 0] + bx[DD6 + 0]; c1 = mean1 + M[0 * MLD + 1] + bx[DD6 + 1]; }
+                    if (scaled) { ns0 = sqrt(bx[DD6 + 2]); ns1 = sqrt(bx[DD6 + 3]); }
+                    // ---- coefficient blocks re-centred at the new mean: Q_kappa(c + eta) in powers of eta
+                    for (int e = tid; e < kNdRows * DD6; e += 256) {
+                        const int row = e / DD6, f = e - row * DD6, al = f / kNdMaxD, be = f - al * kNdMaxD;
+                        const int ea = a.ext[row] & 0xff, eb = a.ext[row] >> 8;
+                        double acc = 0.0;
+                        if (row < a.n_terms_used && al < ea && be < eb) {
+                            const double* bin = Sm + L::oBin;
+                            const double* blk = coef + row * DD;
+                            double pi = 1.0;
+                            for (int i = al; i < ea; ++i) {
+                                double pj = 1.0, rsum = 0.0;
+                                for (int j = be; j < eb; ++j) { rsum = fma(bin[j * NPW + be] * pj, blk[i * a.D + j], rsum); pj *= c1; }
+                                acc = fma(bin[i * NPW + al] * pi, rsum, acc);
+                                pi *= c0;
+                            }
+                        }
+                        qs[e] = acc;
+                    }
+                    // ---- the moment array about the new mean
+                    shift_moments_nd<N>(Sm, npow, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
+                    // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)]
+                    for (int zi = tid; zi < Z; zi += 256) {
+                        int sd = 0;
+                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                        double v = M[n0 * MLD + n1];
+                        for (int k = 0; k < a.n_terms_used; ++k) {
+                            const int k0 = kKap0[k], k1 = kKap1[k];
+                            const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
+                            if (k0 > n0 || k1 > n1 || ea == 0) continue;
+                            const double ff = ffact(n0, k0) * ffact(n1, k1);
+                            const double* q = qs + k * DD6;
+                            const double* Mr = M + (n0 - k0) * MLD + (n1 - k1);
+                            double acc = 0.0;
+                            for (int al = 0; al < ea; ++al)
+                                for (int be = 0; be < eb; ++be) acc = fma(q[al * kNdMaxD + be], Mr[al * MLD + be], acc);
+                            v = fma(ff, acc, v);
+                        }
+                        if (scaled) {
+                            const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
+                            double f = 1.0;
+                            for (int q = 0; q < n0; ++q) f *= i0;
+                            for (int q = 0; q < n1; ++q) f *= i1;
+                            v *= f;
+                        }
+                        mom[zi] = v;
+                        if (!finite(v)) red[16 * ZB] = 1.0;
+                    }
+                    ND_STAMP(6);
                 } else {
-                    py = s4;
-                    if (a.mode != MFS_MODE_RAW) { c0 = s0 / py; c1 = s1 / py; }
-                    nell -= fast_log(py);
-                }
-                ND_STAMP(6);
-                // ---- pass 2: every moment about the new centre.  One node per thread per sweep of the node list; the
-                //      per-node integrands are formed 16 moments at a time (compile-time multi-indices) and each batch
-                //      goes through the transposing row reduction, after which every lane owns one moment summed over
-                //      its 16-lane row and adds it to its slot of the [16 rows][moments] LDS table -- no per-thread
-                //      accumulator array (it would spill) and no value-at-a-time wave sums.
-                const int lane16 = tid & 15;
-                const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
-                double* myred = red + (tid >> 4) * RW + cls;
-                const bool gauss_pred = (TK == 1) && (half == 0);
-                if (gauss_pred) {
-                    // Normal closure: per node, E[(X'_0-c_0)^a (X'_1-c_1)^b] for a + b <= 2N-1 by the Stein recursion
+                    // ---- Normal closure: the s^2 nodes explicitly.  Both K_k diagonalised, weights, then per node the
+                    //      Stein recursion (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), moments.py:110-154)
+                    jacobi_nd<N>(Sm, 0, 2, poisoned ? 0 : warm_mask);
+                    weights_nd<N>(Sm);
+                    warm_mask = poisoned ? 0 : 3;
+                    ND_STAMP_BEGIN;
+                    const double* lam = Sm + L::oLam;
+                    const double* W = Sm + L::oW;
+                    const double qm0 = mean0, qm1 = mean1, qs0 = scale0, qs1 = scale1;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    for (int e = tid; e < R; e += 256) {
+                        const int i0 = e / S, i1 = e - i0 * S;
+                        const double w = W[e];
+                        const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[NP + i1], qs1, qm1);
+                        s0 = fma(w, poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s0);       // mu_0(x)
+                        s1 = fma(w, poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s1);       // mu_1(x)
+                        if (scaled) {  // scale <- sqrt(sum w var_k(x)), filtering.py:186
+                            s2 = fma(w, poly2d(coef + 2 * DD, a.D, a.ext[2], x0, x1), s2);
+                            s3 = fma(w, poly2d(coef + 4 * DD, a.D, a.ext[4], x0, x1), s3);
+                        }
+                    }
+                    s0 = wave_sum64(s0); s1 = wave_sum64(s1);
+                    if (scaled) { s2 = wave_sum64(s2); s3 = wave_sum64(s3); }
+                    if ((tid & 63) == 0) {
+                        double* r3 = red + 4 * RW * (tid >> 6) + 16 * ZB;
+                        r3[1] = s0; r3[2] = s1; r3[4] = s2; r3[5] = s3;
+                    }
+                    __syncthreads();
+                    {
+                        const double* q = red + 16 * ZB;
+                        s0 = q[1] + q[4 * RW + 1] + q[8 * RW + 1] + q[12 * RW + 1];
+                        s1 = q[2] + q[4 * RW + 2] + q[8 * RW + 2] + q[12 * RW + 2];
+                        s2 = q[4] + q[4 * RW + 4] + q[8 * RW + 4] + q[12 * RW + 4];
+                        s3 = q[5] + q[4 * RW + 5] + q[8 * RW + 5] + q[12 * RW + 5];
+                    }
+                    if (!raw) { c0 = s0; c1 = s1; }
+                    if (scaled) { ns0 = sqrt(s2); ns1 = sqrt(s3); }
+                    ND_STAMP(6);
+                    const int lane16 = tid & 15;
+                    const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
+                    double* myred = red + (tid >> 4) * RW + cls;
                     //   M(0,b) = m_1 M(0,b-1) + (b-1) S_11 M(0,b-2)
                     //   M(a,b) = m_0 M(a-1,b) + (a-1) S_00 M(a-2,b) + b S_01 M(a-1,b-1)
-                    // (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), mfs/multi_dims/moments.py:110-154); three
-                    // rows of the table live at a time.  Entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b.
+                    // three rows of the table live at a time; entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b
                     for (int base = 0; base < R; base += 256) {
                         double wA, mA0, mA1, sA00, sA01, sA11;
                         {
@@ -776,133 +993,104 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                             });
                         });
                     }
-                } else if (TK == 0 && half == 0) {
-                    // Operator-table prediction: f_n(x) = sum_kappa Q_kappa(x) d^kappa (x - c)^n factorises over the two
-                    // coordinates,  f_n = sum_{k0 <= 4} [n0!/(n0-k0)! dx0^(n0-k0)] g_{k0}(n1),
-                    //               g_{k0}(n1) = sum_{k1 <= 4-k0} Q_(k0,k1) n1!/(n1-k1)! dx1^(n1-k1)   (Q_(0,0) = 1),
-                    // so a column of moments sharing n1 costs 15 FMAs once plus 5 per moment instead of 15 per moment.
-                    // Entries are emitted column by column: slot e(n1, n0) = n1 P - n1(n1-1)/2 + n0.
-                    for (int base = 0; base < R; base += 256) {
-                        double wA, pxA0[P], pxA1[P], QA[kNdTerms + 1], bt[16];
-                        {
-                            const int eA = base + tid;
-                            const bool okA = eA < R;
-                            const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
-                            wA = okA ? W[eA] : 0.0;
-                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
-                            pxA0[0] = pxA1[0] = 1.0;
+                    __syncthreads();
+                    for (int zi = tid; zi < Z; zi += 256) {
+                        int sd = 0;
+                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                        const int e = n0 * P - n0 * (n0 - 1) / 2 + n1;    // predictions of a Normal closure emit row by row
+                        double v = 0.0;
 #pragma unroll
-                            for (int p = 1; p < P; ++p) { pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1); }
-                            QA[0] = 1.0;   // kappa = (0, 0)
-#pragma unroll
-                            for (int k = 0; k < kNdTerms; ++k)
-                                QA[k + 1] = (k < a.n_terms_used) ? poly2d(coef + k * DD, a.D, a.ext[k], xA0, xA1) : 0.0;
+                        for (int q = 0; q < 16; ++q) v += red[q * RW + e];
+                        if (scaled) {
+                            const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
+                            double f = 1.0;
+                            for (int q = 0; q < n0; ++q) f *= i0;
+                            for (int q = 0; q < n1; ++q) f *= i1;
+                            v *= f;
                         }
-                        static_for<0, P>([&](auto N1c) {
-                            constexpr int n1 = N1c;
-                            double t1[5], g[5];
-                            static_for<0, 5>([&](auto K1c) {
-                                constexpr int k1 = K1c;
-                                if constexpr (k1 <= n1) t1[k1] = ffact(n1, k1) * pxA1[n1 - k1];
-                            });
-                            static_for<0, 5>([&](auto K0c) {
-                                constexpr int k0 = K0c;
-                                double acc = 0.0;
-                                static_for<0, 5 - k0>([&](auto K1c) {
-                                    constexpr int k1 = K1c, sk = k0 + k1;
-                                    if constexpr (k1 <= n1) acc = fma(QA[sk * (sk + 1) / 2 + k0], t1[k1], acc);  // (0,0) -> slot 0
-                                });
-                                g[k0] = acc;
-                            });
-                            static_for<0, P - n1>([&](auto N0c) {
-                                constexpr int n0 = N0c;
-                                double vA = g[0] * pxA0[n0];
-                                static_for<1, 5>([&](auto K0c) {
-                                    constexpr int k0 = K0c;
-                                    if constexpr (k0 <= n0) vA = fma(g[k0] * ffact(n0, k0), pxA0[n0 - k0], vA);
-                                });
-                                constexpr int e = n1 * P - n1 * (n1 - 1) / 2 + n0;
-                                bt[e % 16] = wA * vA;
-                                if constexpr (e % 16 == 15 || e == Z - 1) {
-                                    if constexpr (e % 16 != 15) static_for<e % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
-                                    const double v = row_reduce16(bt, lane16);
-                                    double* slot = myred + 16 * (e / 16);
-                                    *slot = (base == 0) ? v : *slot + v;
-                                }
-                            });
-                        });
+                        mom[zi] = v;
+                        if (!finite(v)) red[16 * ZB] = 1.0;  // slot Z of the first row flags a non-finite moment
                     }
-                } else {
-                    // update (either transition kind): prod_k (x_k - c_k)^{n_k} times the likelihood, in table order; two
-                    // nodes per thread share each row reduction
-                    for (int base = 0; base < R; base += 512) {
-                        double wA, wB, pxA0[P], pxA1[P], pxB0[P], pxB1[P], bt[16];
-                        {
-                            // (the thread index is laundered so that these per-thread indices are recomputed every step:
-                            // hoisted out of the time loop they do not fit in the register budget and come back from
-                            // scratch -- a s_waitcnt vmcnt(0) each)
-                            int tv = tid;
-                            asm volatile("" : "+v"(tv));
-                            const int eA = base + tv, eB = base + 256 + tv;
-                            const bool okA = eA < R, okB = eB < R;
-                            const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
-                            const int iB0 = okB ? eB / S : 0, iB1 = okB ? eB - iB0 * S : 0;
-                            wA = okA ? W[eA] : 0.0;
-                            wB = okB ? W[eB] : 0.0;
-                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
-                            const double xB0 = fma(lam[iB0], qs0, qm0), xB1 = fma(lam[NP + iB1], qs1, qm1);
-                            pxA0[0] = pxA1[0] = pxB0[0] = pxB1[0] = 1.0;
-#pragma unroll
-                            for (int p = 1; p < P; ++p) {
-                                pxA0[p] = pxA0[p - 1] * (xA0 - c0); pxA1[p] = pxA1[p - 1] * (xA1 - c1);
-                                pxB0[p] = pxB0[p - 1] * (xB0 - c0); pxB1[p] = pxB1[p - 1] * (xB1 - c1);
-                            }
-                            wA *= likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? xA0 : xA1);
-                            wB *= likelihood_nd(a.lik_kind, lp, y, a.lik_component == 0 ? xB0 : xB1);
-                        }
-                        static_for<0, 2 * N>([&](auto Sc) {
-                            constexpr int sd = Sc;
-                            static_for<0, sd + 1>([&](auto N0c) {
-                                constexpr int n0 = N0c, n1 = sd - n0, zi = sd * (sd + 1) / 2 + n0;
-                                bt[zi % 16] = fma(wA, pxA0[n0] * pxA1[n1], wB * (pxB0[n0] * pxB1[n1]));
-                                if constexpr (zi % 16 == 15 || zi == Z - 1) {
-                                    if constexpr (zi % 16 != 15) static_for<zi % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
-                                    const double v = row_reduce16(bt, lane16);
-                                    double* slot = myred + 16 * (zi / 16);
-                                    *slot = (base == 0) ? v : *slot + v;
-                                }
-                            });
-                        });
+                    ND_STAMP(7);
+                }
+                if (!raw) { mean0 = c0; mean1 = c1; }
+                if (scaled) { scale0 = ns0; scale1 = ns1; }
+                __syncthreads();
+                bad = bad || (red[16 * ZB] != 0.0);
+                __syncthreads();
+                if (tid == 0) red[16 * ZB] = 0.0;
+            }
+            // =========================================================================================================
+            // update (filtering.py:268-275 / :333-339 / :192-202): bilinear form with h_k = lik_k(X_k) e_0
+            // =========================================================================================================
+            {
+                const bool poisoned = front_nd<N>(Sm, a.inds, a.stable);
+                bad = bad || poisoned;
+                jacobi_nd<N>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
+                warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
+                __syncthreads();
+                ND_STAMP_BEGIN;
+                // ---- g_k[i] = lik_k(x_k,i) V_k[0][i], the spectral coefficients of h_k (or h_k = e_0 where no factor reads
+                //      component k); parked in the rotation records, which are free until the next Jacobi
+                double* g = Sm + L::oCs;
+                if (tid < 2 * S) {
+                    const int k = tid / S, i = tid - k * S;
+                    if ((lik_mask >> k) & 1) {
+                        const double x = fma(Sm[L::oK + k * NP * LD + i * (LD + 1)], k ? scale1 : scale0, k ? mean1 : mean0);
+                        double l = 1.0;
+                        for (int f = 0; f < a.n_factors; ++f)
+                            if (a.fac_comp[f] == k)
+                                l *= likelihood_nd(a.fac_kind[f], Sm + L::oLik + 4 * f, yrow[t * a.ny + a.fac_ycol[f]], x);
+                        g[k * NP + i] = l * Sm[L::oV + k * NP * LD + i];
                     }
                 }
                 __syncthreads();
-                const double ipy = 1.0 / py;
-                // scaled mode: the sums above are central moments about the new mean; the new scales are
-                // sqrt(sum w var_k) on prediction (filtering.py:186) and the posterior standard deviations on update
-                // (:195-197), and every moment is divided by prod_k scale_k^{n_k} -- the same numbers as forming
-                // ((x - mean) / scale)^n per node (:177, :187, :198-200)
-                double ns0 = 1.0, ns1 = 1.0;
-                if (scaled) {
-                    if (half == 0) { ns0 = sqrt(s2); ns1 = sqrt(s3); }
-                    else {
-                        double v5 = 0.0, v3 = 0.0;
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) { v5 += red[q * RW + 5]; v3 += red[q * RW + 3]; }
-                        ns0 = sqrt(v5 * ipy);   // (2, 0)
-                        ns1 = sqrt(v3 * ipy);   // (0, 2)
-                    }
+                // ---- PK[k][p] = X-powers applied to h_k.  Where K_k was diagonalised this is spectral,
+                //      PK[k][p][r] = sum_i V_k[r][i] lambda_i^p g_k[i]  (the tile now holds the eigenvalues, not K_k);
+                //      for the other component it is the Krylov recurrence from e_0 on the intact K_k.
+                double* GL = Sm + L::oM;     // [2][P][NP]: lambda_i^p g_k[i]; M / M2 are free until the moments are formed
+                static_assert(2 * P * NP <= 2 * NPW * MLD, "spectral coefficient table must fit in the M tiles");
+                for (int e = tid; e < 2 * P * S; e += 256) {
+                    const int k = e / (P * S), f = e - k * P * S, p = f / S, i = f - p * S;
+                    if (!((lik_mask >> k) & 1)) continue;
+                    const double lam_i = Sm[L::oK + k * NP * LD + i * (LD + 1)];
+                    double v = g[k * NP + i];
+                    for (int q = 0; q < p; ++q) v *= lam_i;
+                    GL[(k * P + p) * NP + i] = v;
                 }
+                if (tid < 2 * NP && !((lik_mask >> (tid / NP)) & 1))
+                    Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
+                __syncthreads();
+                for (int e = tid; e < 2 * P * S; e += 256) {
+                    const int k = e / (P * S), f = e - k * P * S, p = f / S, r = f - p * S;
+                    if (!((lik_mask >> k) & 1)) continue;
+                    const double* Vr = Sm + L::oV + k * NP * LD + r * LD;
+                    const double* gl = GL + (k * P + p) * NP;
+                    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i + 1 < S; i += 2) { a0 = fma(Vr[i], gl[i], a0); a1 = fma(Vr[i + 1], gl[i + 1], a1); }
+                    if constexpr (S & 1) a0 = fma(Vr[S - 1], gl[S - 1], a0);
+                    Sm[L::oPK + (k * NPW + p) * NP + r] = a0 + a1;
+                }
+                krylov_nd<N>(Sm, P, 3 & ~lik_mask);
+                __syncthreads();
+                bilinear_moments_nd<N>(Sm, P, scale0, scale1);
+                __syncthreads();
+                const double py = M[0];
+                const double ipy = 1.0 / py;
+                double c0 = 0.0, c1 = 0.0;
+                if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
+                nell -= fast_log(py);
+                __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
+                shift_moments_nd<N>(Sm, P, c0 - mean0, c1 - mean1, ipy);
+                double ns0 = 1.0, ns1 = 1.0;
+                if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
                 for (int zi = tid; zi < Z; zi += 256) {
                     int sd = 0;
                     while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
                     const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                    // where pass 2 left this moment: predictions emit row by row (Normal closure) or column by column
-                    const int e = (half != 0) ? zi : (TK == 1) ? n0 * P - n0 * (n0 - 1) / 2 + n1
-                                                              : n1 * P - n1 * (n1 - 1) / 2 + n0;
-                    double v = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) v += red[q * RW + e];
-                    v = (half == 0) ? v : v * ipy;
+                    double v = M[n0 * MLD + n1];
                     if (scaled) {
                         const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
                         double f = 1.0;
@@ -911,18 +1099,14 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                         v *= f;
                     }
                     mom[zi] = v;
-                    if (!finite(v)) red[16 * ZB] = 1.0;  // slot Z of the first row flags a non-finite moment
+                    if (!finite(v)) red[16 * ZB] = 1.0;
                 }
-                if (a.mode != MFS_MODE_RAW) { mean0 = c0; mean1 = c1; }
+                if (!raw) { mean0 = c0; mean1 = c1; }
                 if (scaled) { scale0 = ns0; scale1 = ns1; }
                 __syncthreads();
-                bad = bad || poisoned || (red[16 * ZB] != 0.0);
+                bad = bad || (red[16 * ZB] != 0.0);
                 __syncthreads();
-                if (tid == 0) {   // (a laundered zero: the hoisted constant was living in scratch)
-                    double zero = 0.0;
-                    asm volatile("" : "+v"(zero));
-                    red[16 * ZB] = zero;
-                }
+                if (tid == 0) red[16 * ZB] = 0.0;
                 ND_STAMP(7);
 #ifdef MFS_ND_STAMPS
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
@@ -938,9 +1122,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         __syncthreads();
         if (a.out_mom) {
             double* dst = a.out_mom + ((size_t)b * a.T + t) * Z;
-            int tz = tid;                       // (laundered, as above: no per-thread pointer kept across steps)
-            asm volatile("" : "+v"(tz));
-            for (int zi = tz; zi < Z; zi += 256) dst[zi] = mom[zi];
+            for (int zi = tid; zi < Z; zi += 256) dst[zi] = mom[zi];
         }
         if (tid == 0 && a.out_mean) {
             a.out_mean[((size_t)b * a.T + t) * 2] = mean0;

@@ -1,9 +1,15 @@
 """The N-D moment filters on MI355X, mirroring `mfs.multi_dims.filtering`.
 
 Same names, positional order and return tuples as the reference (mfs/multi_dims/filtering.py:283-288, 210-217,
-33-41); both closure signatures ('multi-index' for sde_cond_moments_tme, 'index' for the Normal closures, :245-249).  d = 2 runs on `filternd_kernel` (mfs_amd/csrc/filternd_kernel.hpp); d = 1 is routed to the 1-D kernels (the
-reference guarantees the d = 1 N-D path equals the 1-D path, tests/test_filtering.py:304-329).  `ys` may carry a leading
-replicate axis (B, T).  No CPU fallback.
+33-41); both closure signatures ('multi-index' for sde_cond_moments_tme, 'index' for the Normal closures, :245-249).
+d = 2 runs on `filternd_kernel` (mfs_amd/csrc/filternd_kernel.hpp); d = 1 is routed to the 1-D kernels (the reference
+guarantees the d = 1 N-D path equals the 1-D path, tests/test_filtering.py:304-329).  Extensions over the reference:
+`ys` may carry a leading replicate axis -- (B, T) for scalar measurements, (B, T, ny) for vector ones -- initial
+moments may be (z,) shared or (B, z), model parameters may be per-replicate.  No CPU fallback.
+
+The measurement likelihood must be a product of factors, each a function of ONE state component and one measurement
+column: `bernoulli.pmf(y, logistic(x[0]))` (mfs/multi_dims/ss_models.py:63-67) or
+`math.prod(norm.pdf(y, x, sd))` on vector y, x (reference tests/test_filtering.py:44-46).
 """
 import ctypes as C
 from typing import Callable, Tuple
@@ -12,19 +18,8 @@ import numpy as np
 
 from mfs_amd import _lib, sym
 from mfs_amd.multi_dims.moments import TransitionRefND
-from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices
-from mfs_amd.tme_poly_nd import GaussianTablesND, TransitionTablesND
 
 __all__ = ['moment_filter_nd_rms', 'moment_filter_nd_cms', 'moment_filter_nd_scms']
-
-
-class _Forbidden:
-    """Stands for a state component the likelihood must not touch while it is traced on another component."""
-
-    def _no(self, *_a, **_k):
-        raise sym.NotDeviceDescribable('the likelihood may depend on one state component only')
-
-    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __pow__ = __neg__ = _no
 
 
 def _trace_transition(fn_and_flag, mode, moments_partial_order=None):
@@ -47,7 +42,7 @@ def _trace_transition(fn_and_flag, mode, moments_partial_order=None):
                                        '_euler_maruyama')
     if not ok:
         raise sym.NotDeviceDescribable('the transition-moment callable does not forward its mean / scale arguments')
-    gaussian = isinstance(ref.tables, GaussianTablesND)
+    gaussian = ref.tables.is_gaussian
     if gaussian != (signature == 'index'):
         raise sym.NotDeviceDescribable(f"signature {signature!r} does not match the closure: the Normal closures take "
                                        "'index', sde_cond_moments_tme takes 'multi-index' "
@@ -62,29 +57,41 @@ def _trace_transition(fn_and_flag, mode, moments_partial_order=None):
 
 
 def _trace_likelihood(fn, d):
-    last = None
-    for c in range(d):
-        x = [sym.X if k == c else _Forbidden() for k in range(d)]
-        try:
-            spec = fn(sym.Y, x)
-        except sym.NotDeviceDescribable as e:
-            last = e
-            continue
-        if isinstance(spec, sym.LikelihoodSpec):
-            spec.component = c
-            return spec
-    raise sym.NotDeviceDescribable(f'measurement_cond_pdf is not device-describable: {last}')
+    """Call the measurement model with the measurement placeholder and the d tagged state components; returns the list
+    of likelihood factors (each with .component and .ycol)."""
+    xs = sym.state_vector(d)
+    spec = fn(sym.Y, xs if d > 1 else xs[0])
+    if isinstance(spec, sym.LikelihoodVector):
+        if len(spec) == 1:
+            spec = spec.factors[0]
+        else:
+            raise sym.NotDeviceDescribable('measurement_cond_pdf returned one value per component; reduce it with '
+                                           'math.prod(...) as the reference does (tests/test_filtering.py:44-46)')
+    if not isinstance(spec, (sym.LikelihoodSpec, sym.LikelihoodProduct)):
+        raise sym.NotDeviceDescribable(
+            f'measurement_cond_pdf returned {type(spec).__name__} when traced; use mfs_amd.stats.bernoulli_pmf / '
+            'poisson_pmf / norm_pdf with mfs_amd.sym.exp / log (mfs_amd has no CPU path for arbitrary callables)')
+    factors = spec.factors
+    if not 1 <= len(factors) <= _lib.ND_MAX_FACTORS:
+        raise sym.NotDeviceDescribable(f'{len(factors)} likelihood factors; the device takes 1..{_lib.ND_MAX_FACTORS}')
+    return factors
 
 
-def _model_struct(tables, lik: sym.LikelihoodSpec):
+def _model_struct(tables, factors, B=1):
     if tables.d != 2:
-        raise sym.NotDeviceDescribable('the device N-D path supports d = 2')
+        raise sym.NotDeviceDescribable('the device N-D kernel is for d = 2')
+    if isinstance(factors, sym.LikelihoodSpec):
+        factors = [factors]
     dense, D = tables.dense_table()
     if D > _lib.ND_MAX_EXTENT:
         raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds MFS_ND_MAX_EXTENT = {_lib.ND_MAX_EXTENT}')
-    coef = np.zeros((_lib.ND_ROWS, D, D))
-    if isinstance(tables, GaussianTablesND):
-        coef[:5] = dense        # mu_0, mu_1, S_00, S_01, S_11
+    batched_coef = dense.ndim == 4          # (B, rows, D, D): per-replicate drift / dispersion parameters
+    if batched_coef and dense.shape[0] != B:
+        raise ValueError(f'transition tables are batched over {dense.shape[0]} replicates, the filter batch is {B}')
+    lead = (B,) if batched_coef else ()
+    coef = np.zeros(lead + (_lib.ND_ROWS, D, D))
+    if tables.is_gaussian:
+        coef[..., :5, :, :] = dense        # mu_0, mu_1, S_00, S_01, S_11
         kind, last = _lib.ND_TRANS_GAUSSIAN, 5
     else:
         kind, last = _lib.ND_TRANS_OPERATOR, 0
@@ -94,39 +101,90 @@ def _model_struct(tables, lik: sym.LikelihoodSpec):
                 raise sym.NotDeviceDescribable(f'derivative term {kap} needs |kappa| <= 4, i.e. tme_order <= 2 on the '
                                                'device')
             row = _lib.ND_KAPPAS.index(kap)
-            coef[row] = dense[t]
+            coef[..., row, :, :] = dense[..., t, :, :]
             last = max(last, row + 1)
-        for k, v in enumerate(tables.var):      # diagonal of tme.mean_and_cov (scaled mode reads it)
-            blk = np.atleast_2d(v.coef)
-            coef[_lib.ND_TERMS + k, :blk.shape[0], :blk.shape[1]] = blk
-    lp = np.ascontiguousarray(lik.params, dtype=np.float64)
-    if lp.ndim != 1:
-        raise sym.NotDeviceDescribable('per-replicate likelihood parameters are not supported on the N-D path yet')
+        coef[..., _lib.ND_TERMS:_lib.ND_TERMS + 2, :, :] = tables.var_blocks(D)   # diagonal of tme.mean_and_cov (scaled mode)
+    # likelihood factors: [n_factors][MAX_LIK], or [B][n_factors][MAX_LIK] when a factor has per-replicate parameters
+    nf = len(factors)
+    lik_batched = any(np.asarray(f.params).ndim > 1 for f in factors)
+    lp = np.zeros(((B,) if lik_batched else ()) + (nf, _lib.MAX_LIK))
+    for i, f in enumerate(factors):
+        prm = np.asarray(f.params, dtype=np.float64)
+        if prm.ndim > 2 or (prm.ndim == 2 and prm.shape[0] != B):
+            raise ValueError(f'likelihood parameters are batched with shape {prm.shape[:-1]}, the filter batch is {B}')
+        lp[..., i, :prm.shape[-1]] = prm
     m = _lib.MfsModelNd()
     m.d, m.n_terms, m.extent = 2, last, D
     m.trans_kind = kind
-    m.lik_kind, m.n_lik, m.lik_component = _lib.LIK[lik.kind], lp.shape[0], lik.component
+    m.n_factors = nf
+    m.ny = max(f.ycol for f in factors) + 1
+    for i, f in enumerate(factors):
+        m.fac_kind[i], m.fac_component[i], m.fac_ycol[i] = _lib.LIK[f.kind], int(f.component), int(f.ycol)
+        m.fac_n_par[i] = int(np.asarray(f.params).shape[-1])
+    m.coef_batched, m.lik_batched = int(batched_coef), int(lik_batched)
+    coef, lp = np.ascontiguousarray(coef), np.ascontiguousarray(lp)
     m.coef = coef.ctypes.data_as(_lib.c_double_p)
     m.lik = lp.ctypes.data_as(_lib.c_double_p)
     return m, (coef, lp)
 
 
-def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, device, scale0=None):
+def _split_ys(ys, ny):
+    """-> (ys (B, T, ny) contiguous float64, squeeze): (T,) / (B, T) for scalar measurements, (T, ny) / (B, T, ny) for
+    vector ones (the reference's ys_2d is (T, 2))."""
+    ys = np.asarray(ys, dtype=np.float64)
+    if ny == 1:
+        if ys.ndim == 3 and ys.shape[-1] == 1:
+            ys = ys[..., 0]
+        if ys.ndim not in (1, 2):
+            raise ValueError(f'ys must have shape (T,) or (B, T) for scalar measurements, got {ys.shape}')
+        squeeze = ys.ndim == 1
+        ys3 = (ys[None, :] if squeeze else ys)[..., None]
+    else:
+        if ys.ndim not in (2, 3) or ys.shape[-1] < ny:
+            raise ValueError(f'ys must have shape (T, {ny}) or (B, T, {ny}) for this likelihood, got {ys.shape}')
+        squeeze = ys.ndim == 2
+        ys3 = (ys[None] if squeeze else ys)[..., :ny]
+    return np.ascontiguousarray(ys3), squeeze
+
+
+def _run_1d(mode, tables, factors, ys, ms0, mean0, scale0, stable, device):
+    """d = 1: the N-D filter IS the 1-D filter (reference tests/test_filtering.py:304-329) -- run the 1-D kernels."""
+    from mfs_amd.one_dim import filtering as f1
+    t1 = tables.as_one_dim()
+    if len(factors) != 1:
+        raise sym.NotDeviceDescribable('a d = 1 filter takes a single likelihood factor')
+    ys = np.asarray(ys, dtype=np.float64)
+    if ys.ndim >= 2 and ys.shape[-1] == 1:
+        ys = ys[..., 0]
+    m0 = None if mean0 is None else np.asarray(mean0, dtype=np.float64)[..., 0]
+    s0 = None if scale0 is None else np.asarray(scale0, dtype=np.float64)[..., 0]
+    m, means, scales, nell, fn = f1._run(mode, t1, factors[0], ms0, m0, s0, ys, stable, device)
+    means = None if means is None else means[..., None]
+    scales = None if scales is None else scales[..., None]
+    if mode == 'scaled':
+        return m, means, scales, nell, fn
+    return m, means, nell, fn
+
+
+def _run_nd(mode, tables, factors, ys, moments_partial_order, ms0, mean0, stable, device, scale0=None):
     multi_indices, inds = moments_partial_order
     multi_indices = np.asarray(multi_indices)
     ms0 = np.ascontiguousarray(ms0, dtype=np.float64)
     if multi_indices.shape[0] != ms0.shape[-1]:  # the reference's only raise (mfs/multi_dims/filtering.py:238-239)
         raise ValueError(f'The size of multi_indices {multi_indices.shape[0]} must match that of cms0 {ms0.shape[-1]}.')
     d = multi_indices.shape[-1]
+    if d != tables.d:
+        raise ValueError(f'the transition closure is {tables.d}-dimensional, the multi-index table {d}-dimensional')
+    if d == 1:
+        return _run_1d(mode, tables, factors, ys, ms0, mean0, scale0, stable, device)
     inds = np.asarray(inds)
     s = inds.shape[1]
     N = next((n for n in range(2, 8) if n * (n + 1) // 2 == s), None)
     if d != 2 or N is None:
-        raise sym.NotDeviceDescribable(f'the device N-D path supports d = 2 with 2 <= N <= 7 (got d = {d}, s = {s})')
-    ys = np.asarray(ys, dtype=np.float64)
-    squeeze = ys.ndim == 1
-    ys2 = np.ascontiguousarray(ys[None, :] if squeeze else ys)
-    B, T = ys2.shape
+        raise sym.NotDeviceDescribable(f'the device N-D path supports d <= 2 with 2 <= N <= 7 (got d = {d}, s = {s})')
+    ny = max(f.ycol for f in factors) + 1
+    ys3, squeeze = _split_ys(ys, ny)
+    B, T = ys3.shape[:2]
     batched = ms0.ndim == 2
     if batched and ms0.shape[0] != B:
         raise ValueError(f'initial moments batch {ms0.shape[0]} does not match ys batch {B}')
@@ -137,7 +195,9 @@ def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, de
     if mode == 'scaled':
         scale_a = np.ascontiguousarray(np.broadcast_to(np.asarray(scale0, dtype=np.float64),
                                                        ((B, 2) if batched else (2,))))
-    model, keep = _model_struct(tables, lik)
+    model, keep = _model_struct(tables, factors, B)
+    if squeeze and (model.coef_batched or model.lik_batched):
+        raise ValueError('per-replicate model parameters need ys with a leading replicate axis')
     mi32 = np.ascontiguousarray(multi_indices, dtype=np.int32)
     inds32 = np.ascontiguousarray(inds, dtype=np.int32)
     out_m = _lib.pinned_empty((B, T, z), device=device)
@@ -145,7 +205,7 @@ def _run_nd(mode, tables, lik, ys, moments_partial_order, ms0, mean0, stable, de
     out_scale = _lib.pinned_empty((B, T, 2), device=device) if mode == 'scaled' else None
     out_nell, out_fn = np.empty((B,)), np.empty((B,), dtype=np.int32)
     _lib.check(_lib.lib().mfs_filter_nd(C.byref(model), _lib.MODE[mode], N, T, B, z, _lib.ptr(mi32), _lib.ptr(inds32),
-                                        _lib.ptr(ms0), int(batched), _lib.ptr(mean_a), _lib.ptr(scale_a), _lib.ptr(ys2),
+                                        _lib.ptr(ms0), int(batched), _lib.ptr(mean_a), _lib.ptr(scale_a), _lib.ptr(ys3),
                                         int(bool(stable)), _lib.ptr(out_m), _lib.ptr(out_mean), _lib.ptr(out_scale),
                                         _lib.ptr(out_nell), _lib.ptr(out_fn), device, None))
     del keep

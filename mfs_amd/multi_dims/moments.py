@@ -8,10 +8,11 @@ from scipy.special import comb as _comb, factorial as _factorial
 
 from mfs_amd import sym
 from mfs_amd.multi_dims.multi_indices import find_indices
-from mfs_amd.tme_poly_nd import TransitionTablesND, GaussianTablesND, tme_tables_nd, normal_tables_nd
+from mfs_amd.tme_poly_nd import (TransitionTablesND, GaussianTablesND, BatchedTablesND, tme_tables_nd,
+                                  normal_tables_nd)
 
 __all__ = ['raw_moments_mvn_kan', 'central_moments_mvn_kan', 'sde_cond_moments_tme', 'sde_cond_moments_tme_normal',
-           'sde_cond_moments_euler_maruyama', 'extract_moments',
+           'sde_cond_moments_euler_maruyama', 'batch_closures', 'extract_moments',
            'extract_mean', 'extract_cov', 'marginalise_moments']
 
 
@@ -127,3 +128,16 @@ def sde_cond_moments_euler_maruyama(drift: Callable, dispersion: Callable, dt: f
     """Euler--Maruyama Normal closure (mfs/multi_dims/moments.py:257-337); 'index' signature."""
     mi = np.asarray(multi_indices)
     return _indexed_five(normal_tables_nd(drift, dispersion, mi.shape[-1], float(dt), 'euler'), mi)
+
+
+def batch_closures(per_replicate):
+    """Stack B closure tuples of one factory (one per replicate, e.g. one per theta of a parameter grid) into a single
+    tuple whose transition tables carry a leading replicate axis -- the N-D counterpart of calling the 1-D factories
+    with array-valued parameters.  The filters then need `ys` of shape (B, T[, ny])."""
+    per_replicate = list(per_replicate)
+    tables = BatchedTablesND([fns[0].tables for fns in per_replicate])
+    first = per_replicate[0]
+    if isinstance(first[0], _CondMomentsNDIndexed):
+        return _indexed_five(tables, first[0].multi_indices)
+    return (_CondMomentsND(tables, 'raw'), _CondMomentsND(tables, 'central'), _CondMomentsND(tables, 'scaled'),
+            _CondMeanND(tables), _CondMeanND(tables, with_var=True))

@@ -8,13 +8,31 @@ import scipy.special
 from mfs_amd import sym
 
 
+def _ycol(y):
+    return getattr(y, 'ycol', None) or 0
+
+
+def _vectorised(fn, y, arg, *rest):
+    """Elementwise likelihood on a vector of symbolic states: entry k pairs y[k] with arg[k]."""
+    if isinstance(arg, (list, tuple, np.ndarray)) and len(arg) and any(sym.is_symbolic(v) for v in np.ravel(arg)):
+        arg = list(np.ravel(arg))
+        ys = [y[k] for k in range(len(arg))] if isinstance(y, sym._Measurement) and y.ycol is None else [y] * len(arg)
+        rests = [[r[k] if isinstance(r, (list, tuple, np.ndarray)) and np.ndim(r) else r for r in rest]
+                 for k in range(len(arg))]
+        return sym.LikelihoodVector([fn(ys[k], arg[k], *rests[k]) for k in range(len(arg))])
+    return None
+
+
 def bernoulli_pmf(y, p):
     """jax.scipy.stats.bernoulli.pmf(y, p) (mfs/one_dim/ss_models.py:46-47, mfs/multi_dims/ss_models.py:66-67)."""
+    vec = _vectorised(bernoulli_pmf, y, p)
+    if vec is not None:
+        return vec
     if isinstance(p, sym._Logistic):
         z = p.z.trimmed()
         if z.umap not in (None, 'x') or z.degree > 3:
             raise sym.NotDeviceDescribable('Bernoulli likelihood: logistic of a polynomial in x of degree <= 3')
-        return sym.LikelihoodSpec('bernoulli_logistic', sym._pad(z.coef, 3), component=getattr(p.z, 'component', 0))
+        return sym.LikelihoodSpec('bernoulli_logistic', sym._pad(z.coef, 3), component=z.comp or 0, ycol=_ycol(y))
     if sym.is_symbolic(p) or sym.is_symbolic(y):
         raise sym.NotDeviceDescribable('bernoulli_pmf: p must be 1 / (1 + exp(-poly(x)))')
     y = np.asarray(y, dtype=np.float64)
@@ -25,11 +43,14 @@ def bernoulli_pmf(y, p):
 
 def poisson_pmf(y, rate):
     """jax.scipy.stats.poisson.pmf(y, rate) (mfs/one_dim/ss_models.py:83-84)."""
+    vec = _vectorised(poisson_pmf, y, rate)
+    if vec is not None:
+        return vec
     if isinstance(rate, sym._Softplus):
         q = rate.q.trimmed()
         if q.umap not in (None, 'x') or q.degree > 1 or np.any(sym._pad(q.coef, 1)[..., 0] != 0.):
             raise sym.NotDeviceDescribable('Poisson likelihood: rate must be log(1 + exp(l * x))')
-        return sym.LikelihoodSpec('poisson_softplus', sym._pad(q.coef, 1)[..., 1:2])
+        return sym.LikelihoodSpec('poisson_softplus', sym._pad(q.coef, 1)[..., 1:2], component=q.comp or 0, ycol=_ycol(y))
     if sym.is_symbolic(rate) or sym.is_symbolic(y):
         raise sym.NotDeviceDescribable('poisson_pmf: rate must be log(1 + exp(l * x))')
     y = np.asarray(y, dtype=np.float64)
@@ -40,13 +61,19 @@ def poisson_pmf(y, rate):
 
 def norm_pdf(y, loc, scale):
     """jax.scipy.stats.norm.pdf(y, loc, scale) (dardel/convergence/convergence_mf.py:58-61)."""
+    vec = _vectorised(norm_pdf, y, loc, scale)
+    if vec is not None:
+        return vec
     if isinstance(loc, sym.Poly):
         q = loc.trimmed()
         if q.umap not in (None, 'x') or q.degree > 1:
             raise sym.NotDeviceDescribable('Gaussian likelihood: loc must be l0 * x + l1')
         c = sym._pad(q.coef, 1)
-        var = np.broadcast_to(np.asarray(scale, dtype=np.float64) ** 2, c.shape[:-1])
-        return sym.LikelihoodSpec('gaussian', np.stack([c[..., 1], c[..., 0], var], axis=-1))
+        var = np.asarray(scale, dtype=np.float64) ** 2
+        lead = np.broadcast_shapes(c.shape[:-1], var.shape)      # per-replicate loc coefficients and / or scale
+        c, var = np.broadcast_to(c, lead + (2,)), np.broadcast_to(var, lead)
+        return sym.LikelihoodSpec('gaussian', np.stack([c[..., 1], c[..., 0], var], axis=-1), component=q.comp or 0,
+                                  ycol=_ycol(y))
     if sym.is_symbolic(loc) or sym.is_symbolic(y):
         raise sym.NotDeviceDescribable('norm_pdf: loc must be l0 * x + l1')
     with np.errstate(all='ignore'):

@@ -31,7 +31,24 @@ class _Placeholder:
         return f'<mfs_amd placeholder {self.name}>'
 
 
-Y = _Placeholder('y')          # the measurement
+class _Measurement(_Placeholder):
+    """The measurement y.  Scalar in the 1-D filters; in the N-D filters it may be a vector (ys of shape (T, ny),
+    reference tests/test_filtering.py:36): `y[k]` is column k, and a likelihood evaluated elementwise on (y, x) pairs
+    column k with state component k."""
+
+    def __init__(self, name='y', ycol=None):
+        super().__init__(name)
+        self.ycol = ycol
+
+    def __getitem__(self, k):
+        if self.ycol is not None:
+            raise NotDeviceDescribable('y[k] is already a scalar column')
+        if isinstance(k, (int, np.integer)):
+            return _Measurement(f'y[{int(k)}]', int(k))
+        raise NotDeviceDescribable('measurements can only be indexed by an integer column')
+
+
+Y = _Measurement()             # the measurement
 ORDER = _Placeholder('order')  # the moment order n
 MEAN = _Placeholder('mean')    # the centre of central / scaled moments
 SCALE = _Placeholder('scale')
@@ -55,11 +72,12 @@ class Poly:
     __array_priority__ = 1000
     __array_ufunc__ = None  # ndarray (op) Poly defers to Poly.__r(op)__; np.sin(Poly) etc. raise TypeError
 
-    def __init__(self, coef, umap=None):
+    def __init__(self, coef, umap=None, comp=None):
         self.coef = np.asarray(coef, dtype=np.float64)
         if self.coef.ndim == 0:
             self.coef = self.coef.reshape(1)
         self.umap = umap
+        self.comp = comp   # N-D likelihood tracing: which state component this expression is a function of (None: any / 1-D)
 
     # -- helpers
     @property
@@ -73,7 +91,14 @@ class Poly:
         c = self.coef
         while c.shape[-1] > 1 and np.all(np.abs(c[..., -1]) <= tol):
             c = c[..., :-1]
-        return Poly(c, self.umap if c.shape[-1] > 1 else None)
+        return Poly(c, self.umap if c.shape[-1] > 1 else None, self.comp)
+
+    @staticmethod
+    def _merge_comp(a, b):
+        if a.comp is not None and b.comp is not None and a.comp != b.comp:
+            raise NotDeviceDescribable('a likelihood factor may depend on one state component only '
+                                       '(write the likelihood as a product of per-component factors)')
+        return a.comp if a.comp is not None else b.comp
 
     @staticmethod
     def _merge_umap(a, b):
@@ -98,12 +123,12 @@ class Poly:
     def __add__(self, o):
         o = Poly.lift(o)
         deg = max(self.degree, o.degree)
-        return Poly(_pad(self.coef, deg) + _pad(o.coef, deg), Poly._merge_umap(self, o))
+        return Poly(_pad(self.coef, deg) + _pad(o.coef, deg), Poly._merge_umap(self, o), Poly._merge_comp(self, o))
 
     __radd__ = __add__
 
     def __neg__(self):
-        return Poly(-self.coef, self.umap)
+        return Poly(-self.coef, self.umap, self.comp)
 
     def __sub__(self, o):
         return self + (-Poly.lift(o))
@@ -119,7 +144,7 @@ class Poly:
         out = np.zeros(shape + (a.shape[-1] + b.shape[-1] - 1,))
         for i in range(a.shape[-1]):
             out[..., i:i + b.shape[-1]] += a[..., i:i + 1] * b
-        return Poly(out, umap)
+        return Poly(out, umap, Poly._merge_comp(self, o))
 
     __rmul__ = __mul__
 
@@ -127,7 +152,7 @@ class Poly:
         o = Poly.lift(o)
         if not o.is_const():
             raise NotDeviceDescribable('division by a non-constant expression')
-        return Poly(self.coef / o.coef[..., :1], self.umap)
+        return Poly(self.coef / o.coef[..., :1], self.umap, self.comp)
 
     def __rtruediv__(self, o):
         raise NotDeviceDescribable('division by a non-constant expression')
@@ -168,6 +193,14 @@ class Poly:
 
 
 X = Poly(np.array([0., 1.]), 'x')  # the state variable
+
+
+def state_vector(d: int) -> np.ndarray:
+    """Object array of the d state components, each tagged with its index (N-D likelihood tracing)."""
+    xs = np.empty((d,), dtype=object)
+    for k in range(d):
+        xs[k] = Poly(np.array([0., 1.]), 'x', comp=k)
+    return xs
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -258,11 +291,64 @@ class LikelihoodSpec:
     """Device description of p(y | x): kind in {'bernoulli_logistic', 'poisson_softplus', 'gaussian'}, params (..., P)."""
     KINDS = {'bernoulli_logistic': 0, 'poisson_softplus': 1, 'gaussian': 2}
 
-    def __init__(self, kind, params, component=0):
+
+
+    def __init__(self, kind, params, component=0, ycol=0):
         assert kind in self.KINDS
         self.kind = kind
         self.params = np.asarray(params, dtype=np.float64)
-        self.component = component  # which state component the likelihood looks at (N-D models)
+        self.component = component  # which state component the factor reads (N-D models)
+        self.ycol = ycol            # which measurement column it reads (N-D models with vector measurements)
+
+    @property
+    def factors(self):
+        return [self]
+
+    def __mul__(self, o):
+        if isinstance(o, numbers.Real) and o == 1:
+            return self
+        if isinstance(o, (LikelihoodSpec, LikelihoodProduct)):
+            return LikelihoodProduct(self.factors + o.factors)
+        raise NotDeviceDescribable('a likelihood can only be multiplied by another likelihood factor')
+
+    __rmul__ = __mul__
 
     def __repr__(self):
-        return f'LikelihoodSpec({self.kind}, params shape {self.params.shape})'
+        return f'LikelihoodSpec({self.kind}, params shape {self.params.shape}, x[{self.component}], y[{self.ycol}])'
+
+
+class LikelihoodProduct:
+    """p(y | x) = prod_f factor_f: what `math.prod(norm.pdf(y, x, sd))` on vector y, x traces to
+    (reference tests/test_filtering.py:44-46)."""
+
+    def __init__(self, factors):
+        self.factors = list(factors)
+
+    def __mul__(self, o):
+        if isinstance(o, numbers.Real) and o == 1:
+            return self
+        if isinstance(o, (LikelihoodSpec, LikelihoodProduct)):
+            return LikelihoodProduct(self.factors + o.factors)
+        raise NotDeviceDescribable('a likelihood can only be multiplied by another likelihood factor')
+
+    __rmul__ = __mul__
+
+    def __repr__(self):
+        return f'LikelihoodProduct({self.factors})'
+
+
+class LikelihoodVector:
+    """Elementwise likelihood of vector measurements / states (one factor per entry); iterable, so that
+    `math.prod(...)` / `np.prod(...)` reduce it to a LikelihoodProduct."""
+
+    def __init__(self, factors):
+        self.factors = list(factors)
+
+    def __iter__(self):
+        return iter(self.factors)
+
+    def __len__(self):
+        return len(self.factors)
+
+    def prod(self, *_a, **_k):
+        return LikelihoodProduct(self.factors)

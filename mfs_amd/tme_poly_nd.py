@@ -145,6 +145,8 @@ def trace_sde_nd(drift, dispersion, d: int) -> Tuple[List[PolyND], List[List[Pol
     zero = PolyND(np.float64(0.), d)
     a = [zero._lift(v) for v in a]
     b = np.asarray(dispersion(xs), dtype=object)
+    if d == 1 and b.ndim < 2:      # a scalar dispersion is a 1 x 1 matrix (the reference's 1-D models return a float)
+        b = b.reshape(1, 1)
     if b.ndim != 2 or b.shape[0] != d:
         raise NotDeviceDescribable('dispersion must return a (d, w) matrix')
     b = [[zero._lift(v) for v in row] for row in b]
@@ -195,8 +197,31 @@ class TransitionTablesND:
     Conditional mean_k = x_k + Q_{e_k}(x).
     """
 
+    is_gaussian = False
+
     def __init__(self, d, kappas, Q, var, label):
         self.d, self.kappas, self.Q, self.var, self.label = d, np.asarray(kappas, dtype=np.int32), Q, var, label
+
+    def var_blocks(self, D):
+        """(d, D, D, ...) coefficient blocks of the conditional variances (diagonal of tme.mean_and_cov)."""
+        out = np.zeros((self.d,) + (D,) * self.d)
+        for k, v in enumerate(self.var):
+            c = v.coef.reshape(v.coef.shape if v.coef.ndim == self.d else (1,) * self.d)
+            out[(k,) + tuple(slice(0, n) for n in c.shape)] = c
+        return out
+
+    def as_one_dim(self):
+        """The same family as a 1-D `mfs_amd.tme_poly.TransitionTables` (d = 1 only): the N-D filter with d = 1 is the
+        1-D filter (reference tests/test_filtering.py:304-329) and runs on the 1-D kernels."""
+        if self.d != 1:
+            raise ValueError('only a d = 1 family has a 1-D form')
+        from mfs_amd.sym import Poly
+        from mfs_amd.tme_poly import TransitionTables
+        K = int(self.kappas.max())
+        Q = [Poly(np.zeros(1), 'x') for _ in range(K)]
+        for kap, q in zip(self.kappas, self.Q):
+            Q[int(kap[0]) - 1] = Poly(np.atleast_1d(q.coef), 'x')
+        return TransitionTables('operator', 'x', Q, 1., Q[0], Poly(np.atleast_1d(self.var[0].coef), 'x'), self.label)
 
     def dense_table(self):
         """(n_terms, D, D, ...) coefficient block with a common per-variable degree bound D - 1."""
@@ -281,8 +306,18 @@ class GaussianTablesND:
     with m = mu(x) - c, which is what the kernel runs per node.
     """
 
+    is_gaussian = True
+
     def __init__(self, d, mean, cov, label):
         self.d, self.mean, self.cov, self.label = d, mean, cov, label
+
+    def as_one_dim(self):
+        if self.d != 1:
+            raise ValueError('only a d = 1 family has a 1-D form')
+        from mfs_amd.sym import Poly
+        from mfs_amd.tme_poly import normal_tables
+        return normal_tables(Poly(np.atleast_1d(self.mean[0].coef), 'x'), Poly(np.atleast_1d(self.cov[0][0].coef), 'x'),
+                             self.label)
 
     def dense_table(self):
         """(5, D, D): mu_0, mu_1, S_00, S_01, S_11."""
@@ -365,3 +400,37 @@ def normal_tables_nd(drift, dispersion, d: int, dt: float, order) -> GaussianTab
                 acc = acc + (dt ** r / math.factorial(r)) * term
             cov[i][j] = acc.trimmed()
     return GaussianTablesND(d, mean, cov, f'tme_normal_{order}')
+
+
+class BatchedTablesND:
+    """B transition families of one kind stacked along a leading replicate axis (per-replicate drift / dispersion
+    parameters: the theta-grid of BASELINE config 4 carried over to the N-D filters).  Built by
+    `mfs_amd.multi_dims.moments.batch_closures`."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        first = self.members[0]
+        if any(m.is_gaussian != first.is_gaussian or m.d != first.d for m in self.members):
+            raise NotDeviceDescribable('batched transition families must be of one kind and dimension')
+        self.d, self.is_gaussian, self.label = first.d, first.is_gaussian, first.label + f' x{len(self.members)}'
+        if not self.is_gaussian:
+            kaps = sorted({tuple(int(v) for v in k) for m in self.members for k in m.kappas}, key=lambda k: (sum(k), k))
+            self.kappas = np.asarray(kaps, dtype=np.int32)
+
+    def dense_table(self):
+        tabs = [m.dense_table() for m in self.members]
+        D = max(t[1] for t in tabs)
+        if self.is_gaussian:
+            out = np.zeros((len(tabs), 5) + (D,) * self.d)
+            for b, (t, _) in enumerate(tabs):
+                out[(b, slice(None)) + tuple(slice(0, n) for n in t.shape[1:])] = t
+            return out, D
+        out = np.zeros((len(tabs), len(self.kappas)) + (D,) * self.d)
+        index = {tuple(int(v) for v in k): i for i, k in enumerate(self.kappas)}
+        for b, (m, (t, _)) in enumerate(zip(self.members, tabs)):
+            for r, kap in enumerate(m.kappas):
+                out[(b, index[tuple(int(v) for v in kap)]) + tuple(slice(0, n) for n in t.shape[1:])] = t[r]
+        return out, D
+
+    def var_blocks(self, D):
+        return np.stack([m.var_blocks(D) for m in self.members])

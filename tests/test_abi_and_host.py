@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f'{name} is declared in include/mfs_hip.h but not exported by libmfs_hip.so'
     assert sorted(_lib.DECLARED_SYMBOLS) == declared, 'ctypes signature table out of sync with the header'
-    assert L.mfs_version() == 1
+    assert L.mfs_version() == _lib.ABI_VERSION == 2
     assert L.mfs_last_error() == b''
 
 

@@ -2,6 +2,8 @@
 the N-D polynomial-ring TME generator against the oracle's SymPy differentiation, Kan moments, model tracing."""
 import os
 
+import math
+
 import numpy as np
 import numpy.testing as npt
 import pytest
@@ -51,10 +53,12 @@ def test_nd_tracing_and_model_struct():
     r, c, s, mu, mv = moments.sde_cond_moments_tme(drift, disp, dt, 2)
     tables = filtering._trace_transition((c, 'multi-index'), 'central')
     lik = filtering._trace_likelihood(pmf, 2)
-    assert lik.kind == 'bernoulli_logistic' and lik.component == 0
-    npt.assert_allclose(lik.params, [-1., 0., 0., 1.])  # 1 / (1 + exp(-x^3 + 1))
+    assert len(lik) == 1 and lik[0].kind == 'bernoulli_logistic' and (lik[0].component, lik[0].ycol) == (0, 0)
+    npt.assert_allclose(lik[0].params, [-1., 0., 0., 1.])  # 1 / (1 + exp(-x^3 + 1))
     m, keep = filtering._model_struct(tables, lik)
-    assert (m.d, m.extent, m.lik_component) == (2, 5, 0) and m.n_terms <= _lib.ND_TERMS
+    assert (m.d, m.extent, m.n_factors, m.ny) == (2, 5, 1, 1) and m.n_terms <= _lib.ND_TERMS
+    assert (m.fac_kind[0], m.fac_component[0], m.fac_ycol[0], m.fac_n_par[0]) == (0, 0, 0, 4)
+    assert (m.coef_batched, m.lik_batched) == (0, 0)
     coef = keep[0]
     # row order is the fixed graded-lex kappa list the kernel unrolls over
     for t, kap in enumerate(tables.kappas):
@@ -114,3 +118,68 @@ def test_nd_normal_closure_tables_match_kan_oracle(order):
         filtering._trace_transition((fns[1], 'index'), 'central', (mi[:-1], None))
     m, keep = filtering._model_struct(tables, filtering._trace_likelihood(pmf, 2))
     assert m.trans_kind == 1 and m.n_terms == 5
+
+
+def test_product_likelihoods_vector_measurements_and_batching():
+    """measurement_cond_pdf_2d of the reference (tests/test_filtering.py:44-46): prod(norm.pdf(y, x, sd)) on vector y, x
+    traces to two Gaussian factors, one per component and measurement column; ys of shape (T, 2) / (B, T, 2)."""
+    import math
+    from mfs_amd import stats
+    factors = filtering._trace_likelihood(lambda y, x: math.prod(stats.norm_pdf(y, x, 1.5)), 2)
+    assert [(f.kind, f.component, f.ycol) for f in factors] == [('gaussian', 0, 0), ('gaussian', 1, 1)]
+    npt.assert_allclose(factors[1].params, [1., 0., 2.25])
+    # explicit columns, a second factor on the same component, per-replicate parameters
+    sd = np.array([0.5, 1.0, 2.0])
+    factors = filtering._trace_likelihood(
+        lambda y, x: stats.norm_pdf(y[1], 2. * x[0] + 1., sd) * stats.bernoulli_pmf(y[0], 1. / (1. + sym.exp(-x[0]))), 2)
+    assert [(f.kind, f.component, f.ycol) for f in factors] == [('gaussian', 0, 1), ('bernoulli_logistic', 0, 0)]
+    mi = mid.generate_graded_lexico_multi_indices(2, 5)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    c = moments.sde_cond_moments_tme(drift, disp, dt, 2)[1]
+    tables = filtering._trace_transition((c, 'multi-index'), 'central')
+    m, (coef, lp) = filtering._model_struct(tables, factors, B=3)
+    assert (m.n_factors, m.ny, m.lik_batched, m.coef_batched) == (2, 2, 1, 0) and lp.shape == (3, 2, _lib.MAX_LIK)
+    npt.assert_allclose(lp[:, 0, :3], np.stack([np.full(3, 2.), np.ones(3), sd ** 2], axis=-1))
+    npt.assert_allclose(lp[:, 1], np.tile([0., 1., 0., 0.], (3, 1)))
+    with pytest.raises(ValueError):
+        filtering._model_struct(tables, factors, B=4)
+    with pytest.raises(sym.NotDeviceDescribable):   # a factor may read one component only
+        filtering._trace_likelihood(lambda y, x: stats.norm_pdf(y, x[0] + x[1], 1.), 2)
+    with pytest.raises(sym.NotDeviceDescribable):   # one value per component must be reduced with prod
+        filtering._trace_likelihood(lambda y, x: stats.norm_pdf(y, x, 1.), 2)
+    # ys layouts
+    ys3, sq = filtering._split_ys(np.zeros((7, 2)), 2)
+    assert ys3.shape == (1, 7, 2) and sq
+    ys3, sq = filtering._split_ys(np.zeros((4, 7)), 1)
+    assert ys3.shape == (4, 7, 1) and not sq
+    with pytest.raises(ValueError):
+        filtering._split_ys(np.zeros((7,)), 2)
+    # per-replicate transition tables: B closure tuples stacked
+    per = []
+    for sig in (0.1, 0.2, 0.3):
+        per.append(moments.sde_cond_moments_tme(drift, lambda x, s=sig: np.array([[s * x[0], 0.], [0., s * x[1]]], dtype=object), dt, 2))
+    fns = moments.batch_closures(per)
+    bt = filtering._trace_transition((fns[1], 'multi-index'), 'central')
+    m, (coef, _) = filtering._model_struct(bt, filtering._trace_likelihood(pmf, 2), B=3)
+    assert m.coef_batched == 1 and coef.shape[0] == 3 and coef.shape[1] == _lib.ND_ROWS
+    _, (single, _) = filtering._model_struct(per[1][1].tables, filtering._trace_likelihood(pmf, 2))
+    npt.assert_array_equal(coef[1][:, :single.shape[1], :single.shape[2]], single)
+
+
+def test_d1_family_has_the_same_tables_as_the_1d_factory():
+    """d = 1: the N-D closure family reduces to the 1-D tables the 1-D kernels run (reference
+    tests/test_filtering.py:304-329, tests/test_one_dim_moments.py:68-88: 1-D vs N-D factories bit-equal)."""
+    from mfs_amd.one_dim import moments as m1
+    ell, sigma, dt = 1., 0.5, 1e-2
+    nd = moments.sde_cond_moments_tme(lambda x: -x / ell, lambda _: math.sqrt(2) * sigma / math.sqrt(ell), dt, 3, d=1)
+    one = m1.sde_cond_moments_tme(lambda x: -x / ell, lambda _: math.sqrt(2) * sigma / math.sqrt(ell), dt, 3)
+    a, _ = nd[1].tables.as_one_dim().table()
+    b, _ = one[1].tables.table()
+    npt.assert_allclose(a, b, rtol=1e-15, atol=1e-300)
+    mi1 = mid.generate_graded_lexico_multi_indices(1, 5)
+    ndn = moments.sde_cond_moments_tme_normal(lambda x: -x / ell, lambda _: math.sqrt(2) * sigma / math.sqrt(ell), dt, 2, mi1)
+    onen = m1.sde_cond_moments_tme_normal(lambda x: -x / ell, lambda _: math.sqrt(2) * sigma / math.sqrt(ell), dt, 2, 3)
+    t = ndn[1].tables.as_one_dim()
+    xs = np.linspace(-1., 1., 5)
+    npt.assert_allclose(t.cond_mean(xs), onen[1].tables.cond_mean(xs), rtol=1e-15)
+    npt.assert_allclose(t.cond_var(xs), onen[1].tables.cond_var(xs), rtol=1e-15)
