@@ -34,7 +34,7 @@ namespace mfs {
 
 #ifdef MFS_ND_STAMPS
 // diagnostic build (tools/diag/nd_stamps.hip): cycles per phase, accumulated by thread 0 of block 0
-__device__ unsigned long long g_nd_stamps[16];
+__device__ unsigned long long g_nd_stamps[24];
 __device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / dia), clamped]: Jacobi convergence tests of block 0
 #define ND_STAMP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now_ = clock64(); g_nd_stamps[slot] += now_ - t_last_; t_last_ = now_; } } while (0)
 #define ND_STAMP_BEGIN unsigned long long t_last_ = clock64()
@@ -74,6 +74,9 @@ constexpr int kNdRows = 16;
 #endif
 // off-diagonal / diagonal mass (squared Frobenius norms) at which the Jacobi sweeps stop
 constexpr double kNdJacobiTol = MFS_ND_JACOBI_TOL;
+#ifndef MFS_ND_FORCE_JACOBI
+#define MFS_ND_FORCE_JACOBI 0   // 1: updates always diagonalise (A/B against the Chebyshev evaluation)
+#endif
 #ifndef MFS_ND_FINISH_X2
 #define MFS_ND_FINISH_X2 1e-14
 #endif
@@ -126,7 +129,16 @@ struct NdTile {
     static constexpr int oBin = oQs + kNdRows * kNdMaxD * kNdMaxD;  // [NPW][NPW] binomial coefficients
     static constexpr int oBx = oBin + NPW * NPW;             // [kNdMaxD][kNdMaxD] raw-monomial sums, then 8 scalars
     static constexpr int oLik = oBx + kNdMaxD * kNdMaxD + 8; // [2][4] likelihood factor parameters
-    static constexpr int kDoubles = oLik + 8;
+    static constexpr int oPw = oLik + 8;                     // [2][NPW] powers of the centre shift
+    // Chebyshev evaluation of lik(X_k) e_0: nodes cos(pi (j + 1/2) / NCH), the cosine table of the coefficient transform,
+    // per-matrix coefficients and scratch ([2] x (coefficients NCH, vector ping-pong 2 NP, 8 scalars))
+    static constexpr int NCH = 32;
+    static constexpr int oChX = (oPw + 2 * NPW + 1) & ~1;    // [NCH]
+    static constexpr int oChC = oChX + NCH;                  // [sample j][coefficient i]: cos(pi i (j + 1/2) / NCH)
+    static constexpr int nChV = (2 * NP > NCH) ? 2 * NP : NCH;   // two vectors of NP, or the NCH samples
+    static constexpr int oChW = oChC + NCH * NCH;            // [2][NCH + nChV + 8]
+    static constexpr int nChW = NCH + nChV + 8;
+    static constexpr int kDoubles = oChW + 2 * nChW;
 };
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -664,9 +676,25 @@ __device__ void weights_nd(double* __restrict__ Sm) {
 // ---------------------------------------------------------------------------------------------------------------------
 // bilinear-form path (identity (*) at the top of this file)
 // ---------------------------------------------------------------------------------------------------------------------
+// Row-times-vector with the vector distributed one entry per lane (lane j holds u_j): v_readlane brings u_j into scalar
+// registers, so a step of a Krylov / Chebyshev recurrence makes no LDS round trip at all.
+template <int S>
+__device__ __forceinline__ double lane_matvec(const double (&kr)[S], const double u) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    static_for<0, S>([&](auto Jc) {
+        constexpr int j = Jc;
+        const double uj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(u), j),
+                                           __builtin_amdgcn_readlane(__double2loint(u), j));
+        if constexpr (j % 3 == 0) a0 = fma(kr[j], uj, a0);
+        else if constexpr (j % 3 == 1) a1 = fma(kr[j], uj, a1);
+        else a2 = fma(kr[j], uj, a2);
+    });
+    return (a0 + a1) + a2;
+}
+
 // Krylov vectors PK[w][p] = K_w^p PK[w][0], p < npow, for the matrices in wmask at once: wave w owns K_w, lane i row i of
-// it in registers; a step is S broadcast LDS reads of the previous vector and S multiply-adds.  No block barrier inside (one
-// wave per chain; LDS executes a wave's accesses in order); the caller synchronises before and after.
+// it in registers; a step is S lane reads of the previous vector and S multiply-adds (lane_matvec).  No block barrier inside (one
+// wave per chain); the caller synchronises before and after.
 template <int N>
 __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask) {
     using L = NdTile<N>;
@@ -678,25 +706,21 @@ __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wma
         double* pk = Sm + L::oPK + w * NPW * NP;
         double kr[S];
         static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
+        wave_sync();
+        double u = pk[li];                        // the start vector, one entry per lane
         for (int p = 1; p < npow; ++p) {
-            wave_sync();
-            const double* u = pk + (p - 1) * NP;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            static_for<0, S>([&](auto Jc) {
-                constexpr int j = Jc;
-                if constexpr (j % 3 == 0) a0 = fma(kr[j], u[j], a0);
-                else if constexpr (j % 3 == 1) a1 = fma(kr[j], u[j], a1);
-                else a2 = fma(kr[j], u[j], a2);
-            });
-            if (lane < S) pk[p * NP + lane] = (a0 + a1) + a2;
+            u = lane_matvec<S>(kr, u);
+            if (lane < S) pk[p * NP + lane] = u;
         }
     }
 }
 
-// M[p][q] = sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow: the moments sum_ij W_ij f_p(xi0_i) g_q(xi1_j) of the rule
-// about its own centre (xi = x - mean = scale * lambda).
+// M[p][q] = sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow with p + q <= maxdeg (the only entries any later stage
+// reads; the rest are zeroed): the moments sum_ij W_ij xi0_i^p xi1_j^q of the rule about its own centre
+// (xi = x - mean = scale * lambda).
 template <int N>
-__device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const double sc0, const double sc1) {
+__device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const int maxdeg, const double sc0,
+                                    const double sc1) {
     using L = NdTile<N>;
     constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD;
     const double* p0 = Sm + L::oPK;
@@ -704,42 +728,187 @@ __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, con
     double* M = Sm + L::oM;
     for (int e = threadIdx.x; e < npow * npow; e += blockDim.x) {
         const int p = e / npow, q = e - p * npow;
-        const double* u = p0 + p * NP;
-        const double* v = p1 + q * NP;
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int j = 0; j + 1 < S; j += 2) { a0 = fma(u[j], v[j], a0); a1 = fma(u[j + 1], v[j + 1], a1); }
-        if constexpr (S & 1) a0 = fma(u[S - 1], v[S - 1], a0);
-        double f = 1.0;
-        for (int k = 0; k < p; ++k) f *= sc0;
-        for (int k = 0; k < q; ++k) f *= sc1;
-        M[p * MLD + q] = (a0 + a1) * f;
+        double v = 0.0;
+        if (p + q <= maxdeg) {
+            const double* u = p0 + p * NP;
+            const double* w = p1 + q * NP;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            static_for<0, S>([&](auto Jc) {
+                constexpr int j = Jc;
+                if constexpr (j % 3 == 0) a0 = fma(u[j], w[j], a0);
+                else if constexpr (j % 3 == 1) a1 = fma(u[j], w[j], a1);
+                else a2 = fma(u[j], w[j], a2);
+            });
+            double f = 1.0;
+            for (int k = 0; k < p; ++k) f *= sc0;
+            for (int k = 0; k < q; ++k) f *= sc1;
+            v = ((a0 + a1) + a2) * f;
+        }
+        M[p * MLD + q] = v;
     }
 }
 
-// M2[a][b] = fac * sum_{j0 <= a, j1 <= b} C(a, j0) (-d0)^(a-j0) C(b, j1) (-d1)^(b-j1) M[j0][j1] for a, b < nout: the
-// same sums about the shifted centre (xi - d).  Two separable passes; M is overwritten by the intermediate.
+// M[a][b] <- fac * sum_{j0 <= a, j1 <= b} C(a, j0) (-d0)^(a-j0) C(b, j1) (-d1)^(b-j1) M[j0][j1] for a + b <= maxdeg: the
+// same sums about the shifted centre (xi - d).  Two separable passes through M2; the powers of -d come from a small LDS
+// table so that the inner loops are plain multiply-adds.
 template <int N>
-__device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const double d0, const double d1, const double fac) {
+__device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const int maxdeg, const double d0,
+                                 const double d1, const double fac) {
     using L = NdTile<N>;
     constexpr int NPW = L::NPW, MLD = L::MLD;
     double* M = Sm + L::oM;
     double* M2 = Sm + L::oM2;
     const double* bin = Sm + L::oBin;
-    for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q]
+    double* pw = Sm + L::oPw;      // [2][NPW]
+    if (threadIdx.x < 2) {
+        const double d = threadIdx.x ? -d1 : -d0;
+        double v = 1.0;
+        for (int k = 0; k < NPW; ++k) { pw[threadIdx.x * NPW + k] = v; v *= d; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q], q <= maxdeg - a
         const int a = e / nout, q = e - a * nout;
-        double acc = 0.0, pw = 1.0;
-        for (int j = a; j >= 0; --j) { acc = fma(bin[a * NPW + j] * pw, M[j * MLD + q], acc); pw *= -d0; }
-        M2[a * MLD + q] = acc;
+        if (a + q > maxdeg) continue;
+        double acc0 = 0.0, acc1 = 0.0;
+        int j = 0;
+        for (; j + 1 <= a; j += 2) {
+            acc0 = fma(bin[a * NPW + j] * pw[a - j], M[j * MLD + q], acc0);
+            acc1 = fma(bin[a * NPW + j + 1] * pw[a - j - 1], M[(j + 1) * MLD + q], acc1);
+        }
+        if (j <= a) acc0 = fma(bin[a * NPW + j] * pw[a - j], M[j * MLD + q], acc0);
+        M2[a * MLD + q] = acc0 + acc1;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
         const int a = e / nout, b = e - a * nout;
-        double acc = 0.0, pw = 1.0;
-        for (int j = b; j >= 0; --j) { acc = fma(bin[b * NPW + j] * pw, M2[a * MLD + j], acc); pw *= -d1; }
-        M[a * MLD + b] = acc * fac;
+        if (a + b > maxdeg) continue;
+        double acc0 = 0.0, acc1 = 0.0;
+        int j = 0;
+        for (; j + 1 <= b; j += 2) {
+            acc0 = fma(bin[b * NPW + j] * pw[NPW + b - j], M2[a * MLD + j], acc0);
+            acc1 = fma(bin[b * NPW + j + 1] * pw[NPW + b - j - 1], M2[a * MLD + j + 1], acc1);
+        }
+        if (j <= b) acc0 = fma(bin[b * NPW + j] * pw[NPW + b - j], M2[a * MLD + j], acc0);
+        M[a * MLD + b] = (acc0 + acc1) * fac;
     }
     __syncthreads();
+}
+
+// h_k = lik_k(X_k) e_0 WITHOUT an eigen-decomposition.  f(K) e_0 equals p(K) e_0 for any polynomial p that matches f on
+// the spectrum; the likelihood factors are analytic, so the Chebyshev interpolant of f(lambda) = lik(y, scale lambda + mean)
+// on a Gershgorin interval [lo, hi] of K converges geometrically and a degree <= 31 reaches rounding level for the
+// models the reference ships (measured on config 5: the coefficients fall below 1e-15 of the largest by degree ~20).
+// The coefficients' tail is CHECKED: if it has not reached 1e-14 of the largest, this returns false in the block-uniform
+// flag and the caller diagonalises K_k instead (cyclic Jacobi) -- the result never silently depends on the truncation.
+//   nodes      lambda_j = mid + half cos(pi (j + 1/2) / NCH)
+//   c_i        = (2 - [i = 0]) / NCH sum_j f(lambda_j) cos(pi i (j + 1/2) / NCH)
+//   h          = sum_i c_i T_i(Khat) e_0,   Khat = (K - mid) / half,  T_{i+1} = 2 Khat T_i - T_{i-1}
+// followed in the same wave by the powers PK[k][p] = K^p h, p < npow.  Wave k works on matrix k (lane i = row i); waves
+// whose component no factor reads run the plain Krylov recurrence from e_0.  No block barrier inside.
+template <int N>
+__device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, const int npow, const int lik_mask,
+                               const double* __restrict__ ysrow, const double mean0, const double mean1,
+                               const double scale0, const double scale1) {
+    using L = NdTile<N>;
+    constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW, NCH = L::NCH;
+    const int tid = threadIdx.x;
+    if (tid >= 128) return;
+    const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
+    const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
+    double* pk = Sm + L::oPK + w * NPW * NP;
+    double* wk = Sm + L::oChW + w * L::nChW;     // [0, NCH) coefficients, then two vectors of NP, then scalars
+    double* cf = wk;
+    double* vbuf = wk + NCH;
+    double* sc = wk + NCH + L::nChV;
+    double kr[S];
+    static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
+    ND_STAMP_BEGIN;
+    if ((lik_mask >> w) & 1) {
+        // ---- Gershgorin interval
+        double dmin, dmax;
+        {
+            double rad = 0.0;
+            static_for<0, S>([&](auto Jc) { rad += fabs(kr[Jc]); });
+            double dg = 0.0;
+            static_for<0, S>([&](auto Jc) { if (Jc == li) dg = kr[Jc]; });
+            rad -= fabs(dg);
+            double lo = (lane < S) ? dg - rad : 1.79e308, hi = (lane < S) ? dg + rad : -1.79e308;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+            dmin = lo; dmax = hi;
+        }
+        const double mid = 0.5 * (dmin + dmax);
+        double half = 0.5 * (dmax - dmin);
+        half = (half > 0.0) ? half : 1.0;
+        const double ihalf = 1.0 / half;
+        ND_STAMP(16);
+        // ---- f at the Chebyshev nodes (lanes < NCH), coefficients by the cosine table
+        {
+            const int j = (lane < NCH) ? lane : 0;
+            const double lam = fma(half, Sm[L::oChX + j], mid);
+            const double x = fma(lam, w ? scale1 : scale0, w ? mean1 : mean0);
+            double f = 1.0;
+            for (int q = 0; q < a.n_factors; ++q)
+                if (a.fac_comp[q] == w) f *= likelihood_nd(a.fac_kind[q], Sm + L::oLik + 4 * q, ysrow[a.fac_ycol[q]], x);
+            if (lane < NCH) vbuf[lane] = f;      // (the vector buffers double as the sample buffer)
+        }
+        wave_sync();
+        {
+            const int i = (lane < NCH) ? lane : 0;
+            const double* ct = Sm + L::oChC + i;         // column i of the [sample][coefficient] table: lanes read consecutive words
+            double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+            for (int j = 0; j < NCH; j += 2) { c0 = fma(vbuf[j], ct[j * NCH], c0); c1 = fma(vbuf[j + 1], ct[(j + 1) * NCH], c1); }
+            const double c = (c0 + c1) * ((i == 0) ? 1.0 / NCH : 2.0 / NCH);
+            // tail and largest coefficient (wave reductions), effective degree
+            double big = (lane < NCH) ? fabs(c) : 0.0, tail = (lane < NCH && lane >= NCH - 3) ? fabs(c) : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { big = fmax(big, __shfl_xor(big, o, 64)); tail = fmax(tail, __shfl_xor(tail, o, 64)); }
+            const bool ok = (tail <= 1e-14 * big) && finite(big);
+            unsigned long long live = __ballot((lane < NCH) && (fabs(c) > 2e-15 * big));   // below: the rounding noise of the transform itself (~1e-15 of the largest)
+            const int deg = ok ? (live ? 63 - __builtin_clzll(live) : 0) : -1;
+            wave_sync();                          // everybody has read the samples
+            if (lane < NCH) cf[lane] = c;
+            if (lane == 0) { sc[0] = (double)deg; }
+        }
+        wave_sync();
+        ND_STAMP(17);
+        const int deg = (int)sc[0];
+        if (deg < 0) {                            // not converged: tell the block, the caller falls back to Jacobi
+            if (lane == 0) Sm[L::oMisc + 6] = 1.0;
+            return;
+        }
+        // ---- h = sum_i c_i T_i(Khat) e_0; row li of Khat is (kr - mid delta) / half
+        static_for<0, S>([&](auto Jc) { kr[Jc] = (kr[Jc] - ((Jc == li) ? mid : 0.0)) * ihalf; });
+        double tprev = (li == 0) ? 1.0 : 0.0;     // T_0 e_0
+        double tcur = kr[0];                      // T_1 e_0 = Khat e_0: column 0 = row 0 (symmetric), entry li
+        double h = fma(cf[1], tcur, cf[0] * tprev);
+        for (int i = 2; i <= deg; ++i) {
+            const double tnext = fma(2.0, lane_matvec<S>(kr, tcur), -tprev);
+            h = fma(cf[i], tnext, h);
+            tprev = tcur; tcur = tnext;
+        }
+        if (deg < 1) h = cf[0] * tprev;
+        if (lane < S) pk[lane] = h;
+        ND_STAMP(18);
+#ifdef MFS_ND_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[20] += deg;
+#endif
+        // ---- powers of K itself: K u = half Khat u + mid u
+        double u = h;
+        for (int p = 1; p < npow; ++p) {
+            u = fma(half, lane_matvec<S>(kr, u), mid * u);
+            if (lane < S) pk[p * NP + lane] = u;
+        }
+        ND_STAMP(19);
+    } else {
+        if (lane < NP) pk[lane] = (lane == 0) ? 1.0 : 0.0;
+        double u = (lane == 0) ? 1.0 : 0.0;
+        for (int p = 1; p < npow; ++p) {
+            u = lane_matvec<S>(kr, u);
+            if (lane < S) pk[p * NP + lane] = u;
+        }
+    }
 }
 
 // TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
@@ -777,6 +946,11 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         double c = (j <= i) ? 1.0 : 0.0;
         for (int k = 1; k <= j && j <= i; ++k) c = c * (double)(i - j + k) / (double)k;
         Sm[L::oBin + e] = c;
+    }
+    for (int e = tid; e < L::NCH * (L::NCH + 1); e += 256) {   // Chebyshev nodes and the cosine table of the coefficient transform
+        constexpr int NCH = L::NCH;
+        if (e < NCH) Sm[L::oChX + e] = cospi(((double)e + 0.5) / NCH);
+        else { const int j = (e - NCH) / NCH, i = (e - NCH) % NCH; Sm[L::oChC + j * NCH + i] = cospi((double)i * ((double)j + 0.5) / NCH); }   // [sample j][coefficient i]
     }
     if (tid < 8) {
         const double* src = a.lik + (a.lik_batched ? (size_t)b * a.n_factors * 4 : 0);
@@ -824,14 +998,23 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     __syncthreads();
                     krylov_nd<N>(Sm, npow, 3);
                     __syncthreads();
-                    bilinear_moments_nd<N>(Sm, npow, scale0, scale1);
+                    ND_STAMP(10);
+                    const int maxdeg = P - 1 + 2 * (a.D - 1);     // highest total degree a re-centred block reaches from a moment
+                    bilinear_moments_nd<N>(Sm, npow, maxdeg, scale0, scale1);
                     __syncthreads();
+                    ND_STAMP(11);
                     // ---- raw-monomial sums Bx[i][j] = sum W x0^i x1^j, x = xi + mean (the conditional means and
                     //      variances are polynomials in x): binomial un-shift of the low corner of M
+                    int bxa = 0, bxb = 0;    // extents of the blocks that read the raw-monomial sums: means and variances
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int row = (r4 < 2) ? r4 : 12 + r4;
+                        if (r4 >= 2 && !scaled) continue;
+                        bxa = max(bxa, a.ext[row] & 0xff); bxb = max(bxb, a.ext[row] >> 8);
+                    }
                     if (tid < DD6) {
                         const int i = tid / kNdMaxD, j = tid - i * kNdMaxD;
                         double acc = 0.0;
-                        if (i < a.D && j < a.D) {
+                        if (i < bxa && j < bxb) {
                             const double* bin = Sm + L::oBin;
                             double pi = 1.0;
                             for (int al = i; al >= 0; --al) {
@@ -856,6 +1039,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     // E[X'_k | x] = x_k + Q_{e_k}(x): the mean of the prediction is the rule's own first moment plus the sum
                     if (!raw) { c0 = mean0 + M[1 * MLD + 0] + bx[DD6 + 0]; c1 = mean1 + M[0 * MLD + 1] + bx[DD6 + 1]; }
                     if (scaled) { ns0 = sqrt(bx[DD6 + 2]); ns1 = sqrt(bx[DD6 + 3]); }
+                    ND_STAMP(12);
                     // ---- coefficient blocks re-centred at the new mean: Q_kappa(c + eta) in powers of eta
                     for (int e = tid; e < kNdRows * DD6; e += 256) {
                         const int row = e / DD6, f = e - row * DD6, al = f / kNdMaxD, be = f - al * kNdMaxD;
@@ -875,34 +1059,55 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                         qs[e] = acc;
                     }
                     // ---- the moment array about the new mean
-                    shift_moments_nd<N>(Sm, npow, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
-                    // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)]
-                    for (int zi = tid; zi < Z; zi += 256) {
-                        int sd = 0;
-                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                        double v = M[n0 * MLD + n1];
-                        for (int k = 0; k < a.n_terms_used; ++k) {
-                            const int k0 = kKap0[k], k1 = kKap1[k];
-                            const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
-                            if (k0 > n0 || k1 > n1 || ea == 0) continue;
-                            const double ff = ffact(n0, k0) * ffact(n1, k1);
-                            const double* q = qs + k * DD6;
-                            const double* Mr = M + (n0 - k0) * MLD + (n1 - k1);
-                            double acc = 0.0;
-                            for (int al = 0; al < ea; ++al)
-                                for (int be = 0; be < eb; ++be) acc = fma(q[al * kNdMaxD + be], Mr[al * MLD + be], acc);
-                            v = fma(ff, acc, v);
+                    ND_STAMP(13);
+                    shift_moments_nd<N>(Sm, npow, maxdeg, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
+                    ND_STAMP(14);
+                    // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)],
+                    //      the kappa terms of a moment spread over four threads (partial sums through the free M2 tile)
+                    {
+                        double* part = Sm + L::oM2;      // [4][Z]
+                        static_assert(4 * Z <= NPW * MLD, "partial sums must fit in the M2 tile");
+                        for (int e = tid; e < 4 * Z; e += 256) {
+                            const int grp = e / Z, zi = e - grp * Z;
+                            int sd = 0;
+                            while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                            const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                            double v = (grp == 0) ? M[n0 * MLD + n1] : 0.0;
+                            for (int k = grp; k < a.n_terms_used; k += 4) {
+                                const int k0 = kKap0[k], k1 = kKap1[k];
+                                const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
+                                if (k0 > n0 || k1 > n1 || ea == 0) continue;
+                                const double* q = qs + k * DD6;
+                                const double* Mr = M + (n0 - k0) * MLD + (n1 - k1);
+                                double acc0 = 0.0, acc1 = 0.0;
+                                for (int al = 0; al < ea; ++al) {
+                                    int be = 0;
+                                    for (; be + 1 < eb; be += 2) {
+                                        acc0 = fma(q[al * kNdMaxD + be], Mr[al * MLD + be], acc0);
+                                        acc1 = fma(q[al * kNdMaxD + be + 1], Mr[al * MLD + be + 1], acc1);
+                                    }
+                                    if (be < eb) acc0 = fma(q[al * kNdMaxD + be], Mr[al * MLD + be], acc0);
+                                }
+                                v = fma(ffact(n0, k0) * ffact(n1, k1), acc0 + acc1, v);
+                            }
+                            part[e] = v;
                         }
-                        if (scaled) {
-                            const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
-                            double f = 1.0;
-                            for (int q = 0; q < n0; ++q) f *= i0;
-                            for (int q = 0; q < n1; ++q) f *= i1;
-                            v *= f;
+                        __syncthreads();
+                        for (int zi = tid; zi < Z; zi += 256) {
+                            int sd = 0;
+                            while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                            const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                            double v = (part[zi] + part[Z + zi]) + (part[2 * Z + zi] + part[3 * Z + zi]);
+                            if (scaled) {
+                                const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
+                                double f = 1.0;
+                                for (int q = 0; q < n0; ++q) f *= i0;
+                                for (int q = 0; q < n1; ++q) f *= i1;
+                                v *= f;
+                            }
+                            mom[zi] = v;
+                            if (!finite(v)) red[16 * ZB] = 1.0;
                         }
-                        mom[zi] = v;
-                        if (!finite(v)) red[16 * ZB] = 1.0;
                     }
                     ND_STAMP(6);
                 } else {
@@ -1027,55 +1232,64 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             {
                 const bool poisoned = front_nd<N>(Sm, a.inds, a.stable);
                 bad = bad || poisoned;
-                jacobi_nd<N>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
-                warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
-                __syncthreads();
+                // h_k = lik_k(X_k) e_0 and the powers K_k^p h_k: Chebyshev evaluation (no eigen-decomposition), checked;
+                // cyclic Jacobi + spectral evaluation only if the coefficients of some factor have not converged
                 ND_STAMP_BEGIN;
-                // ---- g_k[i] = lik_k(x_k,i) V_k[0][i], the spectral coefficients of h_k (or h_k = e_0 where no factor reads
-                //      component k); parked in the rotation records, which are free until the next Jacobi
-                double* g = Sm + L::oCs;
-                if (tid < 2 * S) {
-                    const int k = tid / S, i = tid - k * S;
-                    if ((lik_mask >> k) & 1) {
-                        const double x = fma(Sm[L::oK + k * NP * LD + i * (LD + 1)], k ? scale1 : scale0, k ? mean1 : mean0);
-                        double l = 1.0;
-                        for (int f = 0; f < a.n_factors; ++f)
-                            if (a.fac_comp[f] == k)
-                                l *= likelihood_nd(a.fac_kind[f], Sm + L::oLik + 4 * f, yrow[t * a.ny + a.fac_ycol[f]], x);
-                        g[k * NP + i] = l * Sm[L::oV + k * NP * LD + i];
+                if (tid == 0) Sm[L::oMisc + 6] = 0.0;
+                __syncthreads();
+                cheb_krylov_nd<N>(Sm, a, P, MFS_ND_FORCE_JACOBI ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
+                __syncthreads();
+                if (MFS_ND_FORCE_JACOBI || Sm[L::oMisc + 6] != 0.0) {
+                    jacobi_nd<N>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
+                    warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
+                    __syncthreads();
+                    // ---- g_k[i] = lik_k(x_k,i) V_k[0][i], the spectral coefficients of h_k (or h_k = e_0 where no factor reads
+                    //      component k); parked in the rotation records, which are free until the next Jacobi
+                    double* g = Sm + L::oCs;
+                    if (tid < 2 * S) {
+                        const int k = tid / S, i = tid - k * S;
+                        if ((lik_mask >> k) & 1) {
+                            const double x = fma(Sm[L::oK + k * NP * LD + i * (LD + 1)], k ? scale1 : scale0, k ? mean1 : mean0);
+                            double l = 1.0;
+                            for (int f = 0; f < a.n_factors; ++f)
+                                if (a.fac_comp[f] == k)
+                                    l *= likelihood_nd(a.fac_kind[f], Sm + L::oLik + 4 * f, yrow[t * a.ny + a.fac_ycol[f]], x);
+                            g[k * NP + i] = l * Sm[L::oV + k * NP * LD + i];
+                        }
                     }
+                    __syncthreads();
+                    // ---- PK[k][p] = X-powers applied to h_k.  Where K_k was diagonalised this is spectral,
+                    //      PK[k][p][r] = sum_i V_k[r][i] lambda_i^p g_k[i]  (the tile now holds the eigenvalues, not K_k);
+                    //      for the other component it is the Krylov recurrence from e_0 on the intact K_k.
+                    double* GL = Sm + L::oM;     // [2][P][NP]: lambda_i^p g_k[i]; M / M2 are free until the moments are formed
+                    static_assert(2 * P * NP <= 2 * NPW * MLD, "spectral coefficient table must fit in the M tiles");
+                    for (int e = tid; e < 2 * P * S; e += 256) {
+                        const int k = e / (P * S), f = e - k * P * S, p = f / S, i = f - p * S;
+                        if (!((lik_mask >> k) & 1)) continue;
+                        const double lam_i = Sm[L::oK + k * NP * LD + i * (LD + 1)];
+                        double v = g[k * NP + i];
+                        for (int q = 0; q < p; ++q) v *= lam_i;
+                        GL[(k * P + p) * NP + i] = v;
+                    }
+                    if (tid < 2 * NP && !((lik_mask >> (tid / NP)) & 1))
+                        Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
+                    __syncthreads();
+                    for (int e = tid; e < 2 * P * S; e += 256) {
+                        const int k = e / (P * S), f = e - k * P * S, p = f / S, r = f - p * S;
+                        if (!((lik_mask >> k) & 1)) continue;
+                        const double* Vr = Sm + L::oV + k * NP * LD + r * LD;
+                        const double* gl = GL + (k * P + p) * NP;
+                        double a0 = 0.0, a1 = 0.0;
+    #pragma unroll
+                        for (int i = 0; i + 1 < S; i += 2) { a0 = fma(Vr[i], gl[i], a0); a1 = fma(Vr[i + 1], gl[i + 1], a1); }
+                        if constexpr (S & 1) a0 = fma(Vr[S - 1], gl[S - 1], a0);
+                        Sm[L::oPK + (k * NPW + p) * NP + r] = a0 + a1;
+                    }
+                    krylov_nd<N>(Sm, P, 3 & ~lik_mask);
+                    __syncthreads();
                 }
-                __syncthreads();
-                // ---- PK[k][p] = X-powers applied to h_k.  Where K_k was diagonalised this is spectral,
-                //      PK[k][p][r] = sum_i V_k[r][i] lambda_i^p g_k[i]  (the tile now holds the eigenvalues, not K_k);
-                //      for the other component it is the Krylov recurrence from e_0 on the intact K_k.
-                double* GL = Sm + L::oM;     // [2][P][NP]: lambda_i^p g_k[i]; M / M2 are free until the moments are formed
-                static_assert(2 * P * NP <= 2 * NPW * MLD, "spectral coefficient table must fit in the M tiles");
-                for (int e = tid; e < 2 * P * S; e += 256) {
-                    const int k = e / (P * S), f = e - k * P * S, p = f / S, i = f - p * S;
-                    if (!((lik_mask >> k) & 1)) continue;
-                    const double lam_i = Sm[L::oK + k * NP * LD + i * (LD + 1)];
-                    double v = g[k * NP + i];
-                    for (int q = 0; q < p; ++q) v *= lam_i;
-                    GL[(k * P + p) * NP + i] = v;
-                }
-                if (tid < 2 * NP && !((lik_mask >> (tid / NP)) & 1))
-                    Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
-                __syncthreads();
-                for (int e = tid; e < 2 * P * S; e += 256) {
-                    const int k = e / (P * S), f = e - k * P * S, p = f / S, r = f - p * S;
-                    if (!((lik_mask >> k) & 1)) continue;
-                    const double* Vr = Sm + L::oV + k * NP * LD + r * LD;
-                    const double* gl = GL + (k * P + p) * NP;
-                    double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-                    for (int i = 0; i + 1 < S; i += 2) { a0 = fma(Vr[i], gl[i], a0); a1 = fma(Vr[i + 1], gl[i + 1], a1); }
-                    if constexpr (S & 1) a0 = fma(Vr[S - 1], gl[S - 1], a0);
-                    Sm[L::oPK + (k * NPW + p) * NP + r] = a0 + a1;
-                }
-                krylov_nd<N>(Sm, P, 3 & ~lik_mask);
-                __syncthreads();
-                bilinear_moments_nd<N>(Sm, P, scale0, scale1);
+                ND_STAMP(15);
+                bilinear_moments_nd<N>(Sm, P, P - 1, scale0, scale1);
                 __syncthreads();
                 const double py = M[0];
                 const double ipy = 1.0 / py;
@@ -1083,7 +1297,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
                 nell -= fast_log(py);
                 __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
-                shift_moments_nd<N>(Sm, P, c0 - mean0, c1 - mean1, ipy);
+                shift_moments_nd<N>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
                 for (int zi = tid; zi < Z; zi += 256) {

@@ -4,7 +4,7 @@ oracle/__init__.py): per-quantity relative errors between two runs of the same f
 Conventions
   * errors are taken over the filter-steps that are finite in BOTH runs;
   * a moment of order n is compared relative to max(|ref|, floor_n) where floor_n = 1e-3 x the largest magnitude the
-    moments of order n and n + 1 reach over the run (odd central moments of near-symmetric laws and cms[1] are rounding
+    moments of orders n - 1, n and n + 1 reach over the run (odd central moments of near-symmetric laws and cms[1] are rounding
     noise around zero: a pure relative error is meaningless there) -- the same scaling the parity tests use;
   * first-NaN step = index of the first step with a non-finite output, T if the replicate survives.
 """
@@ -23,7 +23,8 @@ def moment_floor(ref):
     """(2N,) per-order magnitude floor from a (..., 2N) array of reference moments."""
     flat = np.abs(np.asarray(ref).reshape(-1, ref.shape[-1]))
     colmax = np.nanmax(np.where(np.isfinite(flat), flat, 0.), axis=0)
-    neighbour = np.maximum(colmax, np.concatenate([colmax[1:], colmax[-1:]]))
+    neighbour = np.maximum(colmax, np.maximum(np.concatenate([colmax[1:], colmax[-1:]]),
+                                              np.concatenate([colmax[:1], colmax[:-1]])))
     return neighbour * 1e-3 + 1e-300
 
 

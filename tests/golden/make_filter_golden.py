@@ -28,7 +28,10 @@ import os
 import sys
 import time
 
-import numpy as np
+for _v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):   # forked workers + threaded BLAS deadlock
+    os.environ.setdefault(_v, '1')
+
+import numpy as np  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))

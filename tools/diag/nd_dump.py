@@ -12,6 +12,6 @@ m, keep = filtering._model_struct(t, l)
 ys,_ = synth.prey_predator_batch(B, T, dt, seed=0)
 with open('tools/diag/nd_case.bin','wb') as f:
     f.write(struct.pack('6i', T, B, m.extent, m.n_terms, mi.shape[0], inds.shape[1]))
-    f.write(keep[0].tobytes()); f.write(np.pad(keep[1], (0, 4-len(keep[1]))).astype(np.float64).tobytes())
+    f.write(keep[0].tobytes()); f.write(np.ascontiguousarray(keep[1][0], dtype=np.float64).tobytes())   # the single likelihood factor's [4] parameters
     f.write(inds.astype(np.int32).tobytes()); f.write(gs.cms.tobytes()); f.write(gs.mean.tobytes()); f.write(ys.tobytes())
 print('dumped')

@@ -19,17 +19,22 @@ int main(int argc, char** argv) {
     hipMemcpy(dc, coef.data(), coef.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dl, lik.data(), 32, hipMemcpyHostToDevice);
     hipMemcpy(dm, m0.data(), z * 8, hipMemcpyHostToDevice); hipMemcpy(dmean, mean0.data(), 16, hipMemcpyHostToDevice);
     hipMemcpy(dys, ys.data(), ys.size() * 8, hipMemcpyHostToDevice); hipMemcpy(di, inds.data(), inds.size() * 4, hipMemcpyHostToDevice);
-    FilterNdArgs a{}; a.mode = 1; a.T = T; a.B = B; a.stable = 0; a.n_terms_used = nt; a.D = D; a.lik_kind = 0; a.n_lik = 4;
-    a.lik_component = 0; for (int k = 0; k < kNdRows; ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
+    FilterNdArgs a{}; a.mode = 1; a.T = T; a.B = B; a.stable = 0; a.n_terms_used = nt; a.D = D; a.n_factors = 1; a.ny = 1;
+    a.fac_kind[0] = 0; a.fac_comp[0] = 0; a.fac_ycol[0] = 0; for (int k = 0; k < kNdRows; ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
     a.out_mom = nullptr; a.out_mean = dmeans; a.out_nell = dnell; a.out_first_nan = nullptr;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((filternd_kernel<N, 0>), dim3(B), dim3(256), NdTile<N>::kDoubles * 8, 0, a);
     hipDeviceSynchronize();
-    unsigned long long st[16]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
-    const char* names[] = {"gather", "cholesky", "trsm+sym", "warm-start matmuls", "jacobi sweeps", "weights", "pass1 sums", "pass2 moments+reduce"};
+    unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
+    const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
     double tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
-    printf("half-steps %llu, sweeps %llu (%.2f per quadrature)\n", st[9], st[8], (double)st[8] / st[9]);
-    for (int i = 0; i < 8; ++i) printf("%-24s %10.0f cycles per half-step  %5.1f %%\n", names[i], (double)st[i] / st[9], 100.0 * st[i] / tot);
+    printf("steps %llu, Jacobi sweeps %llu (%.2f per update rule; one matrix)\n", st[9], st[8], (double)st[8] / st[9]);
+    for (int i = 0; i < 8; ++i) printf("%-24s %10.0f cycles per step  %5.1f %%\n", names[i], (double)st[i] / st[9], 100.0 * st[i] / tot);
+    const char* sub[] = {"  predict: krylov", "  predict: moment array", "  predict: means", "  predict: re-centred coefficients", "  predict: shift", "  update: Chebyshev h + powers (or Jacobi)"};
+    for (int i = 0; i < 6; ++i) printf("%-36s %10.0f cycles per step\n", sub[i], (double)st[10 + i] / st[9]);
+    const char* sub2[] = {"    cheb: Gershgorin", "    cheb: samples + coefficients", "    cheb: recurrence", "    cheb: powers"};
+    for (int i = 0; i < 4; ++i) printf("%-36s %10.0f cycles per step\n", sub2[i], (double)st[16 + i] / st[9]);
+    printf("    mean Chebyshev degree %.1f\n", (double)st[20] / st[9]);
     unsigned long long hist[8][40]; hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_nd_hist), sizeof(hist));
     for (int t = 0; t < 8; ++t) {
         unsigned long long n = 0; for (int k = 0; k < 40; ++k) n += hist[t][k];
