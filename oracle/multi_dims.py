@@ -117,8 +117,11 @@ def moment_quadrature_nd(ms: np.ndarray, inds: np.ndarray, mean: np.ndarray = No
     eigvals = np.zeros((d, n))
     eigvecs = np.zeros((d, n, n))
     for k in range(d):
-        X = scipy.linalg.solve_triangular(R, Hs[k], lower=True, check_finite=False)
-        K = scipy.linalg.solve_triangular(R, X.T, lower=True, check_finite=False).T
+        try:
+            X = scipy.linalg.solve_triangular(R, Hs[k], lower=True, check_finite=False)
+            K = scipy.linalg.solve_triangular(R, X.T, lower=True, check_finite=False).T
+        except np.linalg.LinAlgError:   # exactly zero diagonal of a completed factor: inf / NaN in-band upstream
+            return np.full((r,), np.nan), np.full((r, d), np.nan)
         eigvals[k], eigvecs[k] = _eigh_nan(K)
     combs = nd_cartesian_prod_indices(d, n)
     # combs_eigvectors[c, row, k] = eigvecs[k, row, combs[c, k]]; combs_eigvals[c, k] = eigvals[k, combs[c, k]]

@@ -90,8 +90,12 @@ def moment_quadrature(ms: np.ndarray, mean: float = 0., scale: float = 1., ldl: 
     if not np.all(np.isfinite(R)):
         nan = np.full((n,), np.nan)
         return nan, nan.copy()
-    X = scipy.linalg.solve_triangular(R, H, lower=True, check_finite=False)  # R X = H
-    K = scipy.linalg.solve_triangular(R, X.T, lower=True, check_finite=False).T  # K R^T = X
+    try:
+        X = scipy.linalg.solve_triangular(R, H, lower=True, check_finite=False)  # R X = H
+        K = scipy.linalg.solve_triangular(R, X.T, lower=True, check_finite=False).T  # K R^T = X
+    except np.linalg.LinAlgError:   # an exactly zero diagonal (ldl=True with d_j == 0): XLA divides and yields inf / NaN in-band
+        nan = np.full((n,), np.nan)
+        return nan, nan.copy()
     vals, vecs = _eigh_nan(K)
     return vecs[0, :] ** 2, scale * vals + mean
 

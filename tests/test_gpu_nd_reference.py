@@ -1,0 +1,181 @@
+"""The reference's own N-D filter tests (tests/test_filtering.py:169-329) restated ON THE DEVICE: vector measurements
+ys_2d (T, 2), the product likelihood measurement_cond_pdf_2d = prod(norm.pdf(y, x, sd)) (:36-46), the three-mode
+equivalence (:169-242), independent 2-D == two 1-D filters with nell_2d == 2 nell_1d (:244-302) and the d = 1 N-D call
+equal to the 1-D filter (:304-329).  Measurements are the reference's (np.random.seed(666), :17-31).  Where the
+reference uses TME-3 with the 'multi-index' closure the device's operator path takes TME-2 (|kappa| <= 4); the property
+under test does not depend on the order.  Every device result is also compared with the oracle.
+"""
+import math
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from mfs_amd import stats, synth
+from mfs_amd.multi_dims import filtering, moments
+from mfs_amd.multi_dims.moments import raw_moments_mvn_kan, central_moments_mvn_kan, marginalise_moments
+from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, gram_and_hankel_indices_graded_lexico
+from mfs_amd.one_dim import filtering as f1, moments as m1
+from oracle import multi_dims as omd, one_dim as o, tme_sympy, models as om
+
+pytestmark = pytest.mark.gpu
+
+dt, T = 1e-2, 100
+ell, sigma = 1., 0.5
+b_const = math.sqrt(2) * sigma / math.sqrt(ell)
+
+
+def _measurements():
+    np.random.seed(666)
+    ts = np.linspace(dt, dt * T, T)
+    cov = np.exp(-np.abs(ts[None, :] - ts[:, None]) / ell) * sigma ** 2
+    ys = np.linalg.cholesky(cov) @ np.random.randn(T) + np.random.randn(T)
+    return ys, np.stack([ys, ys], axis=-1)
+
+
+def drift(x):
+    return -x / ell
+
+
+def dispersion_2d(_):
+    return b_const * np.eye(2)
+
+
+def measurement_cond_pdf(y, x):
+    return stats.norm_pdf(y, x, 1.)
+
+
+def measurement_cond_pdf_2d(y, x):
+    return math.prod(stats.norm_pdf(y, x, 1.))
+
+
+def o_pdf_2d(y, x):
+    return float(np.prod(om.norm_pdf(y, x, 1.)))
+
+
+def test_nd_routines_equivalence_tme_normal_index():
+    """:169-242 -- rms / cms / scms with the TME-normal-2 'index' closures, vector measurements, product likelihood."""
+    ys, ys_2d = _measurements()
+    d, N, order = 2, 3, 2
+    mi = generate_graded_lexico_multi_indices(d, 2 * N - 1, 0)
+    inds = gram_and_hankel_indices_graded_lexico(N, d)
+    fns = moments.sde_cond_moments_tme_normal(drift, dispersion_2d, dt, order, mi)
+    mean0, cov0 = np.array([1., 1.]), np.eye(d)
+    scale0 = np.sqrt(np.diag(cov0))
+    rms0 = np.array([raw_moments_mvn_kan(mean0, cov0, m) for m in mi])
+    cms0 = np.array([central_moments_mvn_kan(cov0, m) for m in mi])
+    scms0 = cms0 / np.array([np.prod(scale0 ** m) for m in mi])
+    rmss, nell_r = filtering.moment_filter_nd_rms((fns[0], 'index'), measurement_cond_pdf_2d, ys_2d, (mi, inds), rms0)
+    cmss, means_c, nell_c = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], measurement_cond_pdf_2d, ys_2d,
+                                                           (mi, inds), cms0, mean0)
+    scmss, means_s, scales_s, nell_s = filtering.moment_filter_nd_scms((fns[2], 'index'), fns[4], measurement_cond_pdf_2d,
+                                                                       ys_2d, (mi, inds), scms0, mean0, scale0)
+    assert rmss.shape == (T, mi.shape[0]) and means_c.shape == (T, 2) and np.ndim(nell_r) == 0
+    # the reference's assertions (:229-242), its tolerances
+    npt.assert_allclose(means_s, means_c, atol=1e-12, rtol=1e-12)
+    npt.assert_allclose(rmss[:, 1], means_c[:, 1], atol=1e-10, rtol=1e-8)
+    npt.assert_allclose(rmss[:, 2], means_c[:, 0], atol=1e-10, rtol=1e-8)
+    npt.assert_allclose(rmss[:, 3] - rmss[:, 1] ** 2, scales_s[:, 1] ** 2, atol=1e-11, rtol=1e-10)
+    npt.assert_allclose(rmss[:, 5] - rmss[:, 2] ** 2, scales_s[:, 0] ** 2, atol=1e-11, rtol=1e-10)
+    for n, m in enumerate(mi):
+        npt.assert_allclose(cmss[:, n], scmss[:, n] * np.prod(scales_s ** m, axis=1), atol=1e-13)
+    for nell in (nell_c, nell_s):
+        npt.assert_array_almost_equal(nell_r, nell, decimal=10)
+    # and against the oracle
+    orms, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(lambda x: [-x[0] / ell, -x[1] / ell],
+                                                             lambda x: [[b_const, 0], [0, b_const]], d, dt, order, mi)
+    rc = omd.moment_filter_nd_cms((ocms, 'index'), omean, o_pdf_2d, ys_2d, (mi, inds), cms0, mean0)
+    npt.assert_allclose(nell_c, rc[2], rtol=1e-9)
+    npt.assert_allclose(means_c, rc[1], rtol=1e-8, atol=1e-11)
+    npt.assert_allclose(cmss, rc[0], rtol=1e-6, atol=1e-10)
+    # batched: the same trajectory twice and a shifted one, (B, T, 2)
+    ysB = np.stack([ys_2d, ys_2d, ys_2d + 0.1])
+    cB, mB, nB = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], measurement_cond_pdf_2d, ysB, (mi, inds), cms0,
+                                                mean0)
+    npt.assert_array_equal(cB[0], cmss)
+    npt.assert_array_equal(cB[1], cmss)
+    assert nB[2] != nB[0]
+
+
+def test_independent_2d_reduces_to_two_1d_filters_and_d1_is_the_1d_filter():
+    """:244-329."""
+    ys, ys_2d = _measurements()
+    N, order, m0, var0 = 3, 2, 0.1, 0.2
+    f1d = m1.sde_cond_moments_tme(drift, lambda _: b_const, dt, order)
+    rms0_1d = np.array([float(m1.raw_moment_of_normal(m0, var0, p)) for p in range(2 * N)])
+    rmss_1d, nell_1d = f1.moment_filter_rms(f1d[0], measurement_cond_pdf, rms0_1d, ys)
+    d = 2
+    mi = generate_graded_lexico_multi_indices(d, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, d)
+    fnd = moments.sde_cond_moments_tme(drift, dispersion_2d, dt, order)
+    rms0 = np.array([raw_moments_mvn_kan(m0 * np.ones(d), var0 * np.eye(d), m) for m in mi])
+    rmss_2d, nell_2d = filtering.moment_filter_nd_rms((fnd[0], 'multi-index'), measurement_cond_pdf_2d, ys_2d, (mi, inds),
+                                                      rms0)
+    npt.assert_allclose(rms0_1d, marginalise_moments(rms0, d, N, 0))
+    npt.assert_allclose(marginalise_moments(rmss_2d, d, N, 0), marginalise_moments(rmss_2d, d, N, 1))
+    # (rtol 1e-3 is the reference's bar for "the numerical errors due to e.g. Cholesky, eigh"; what it measures is the
+    #  difference between the 3-node 1-D rule and the marginal of the 36-node 2-D rule on the non-polynomial Gaussian
+    #  likelihood -- a property of the algorithm, the same in the oracle -- so the odd raw moments, which pass through zero
+    #  on this data at TME order 2, get an absolute floor)
+    npt.assert_allclose(rmss_1d, marginalise_moments(rmss_2d, d, N, 0), rtol=1e-3, atol=2e-4)
+    # :302 asserts nell_2d == 2 nell_1d to 1e-7 at TME-3, where the oracle has 2.6e-8; at TME-2 the identity itself holds
+    # to 1.03e-6 only (oracle: 2 x 151.8192099 vs 303.6387340 -- a property of the truncated 2-D rule, reproduced here)
+    npt.assert_allclose(nell_1d * 2, nell_2d, rtol=2e-6)
+    # oracle
+    orms, *_ = tme_sympy.sde_cond_moments_tme_nd(lambda x: [-x[0] / ell, -x[1] / ell], lambda x: [[b_const, 0], [0, b_const]],
+                                                 d, dt, order, mi)
+    rr = omd.moment_filter_nd_rms((orms, 'multi-index'), o_pdf_2d, ys_2d, (mi, inds), rms0)
+    npt.assert_allclose(nell_2d, rr[1], rtol=1e-9)
+    npt.assert_allclose(rmss_2d, rr[0], rtol=1e-6, atol=1e-12)
+    # d = 1 through the N-D entry point: exactly the 1-D implementation (:304-329)
+    mi1 = generate_graded_lexico_multi_indices(1, 2 * N - 1, 0)
+    inds1 = gram_and_hankel_indices_graded_lexico(N, 1)
+    fext = moments.sde_cond_moments_tme(drift, lambda _: b_const, dt, order, d=1)
+    rms0_e = np.array([raw_moments_mvn_kan(m0 * np.ones(1), var0 * np.eye(1), m) for m in mi1])
+    rmss_ext, nell_ext = filtering.moment_filter_nd_rms((fext[0], 'multi-index'), measurement_cond_pdf, ys, (mi1, inds1),
+                                                        rms0_e)
+    npt.assert_allclose(rmss_ext, rmss_1d)
+    npt.assert_allclose(nell_ext, nell_1d)
+    # central and scaled d = 1 calls return (T, 1) means / scales like the reference's N-D filters
+    cms0 = m1.raw_to_central(rms0_1d)
+    c1, mean1, n1 = f1.moment_filter_cms(f1d[1], f1d[3], measurement_cond_pdf, cms0, m0, ys)
+    ce, me, ne = filtering.moment_filter_nd_cms((fext[1], 'multi-index'), fext[3], measurement_cond_pdf, ys, (mi1, inds1),
+                                                cms0, np.array([m0]))
+    assert me.shape == (T, 1)
+    npt.assert_allclose(ce, c1, rtol=1e-12, atol=1e-15)
+    npt.assert_allclose(me[:, 0], mean1, rtol=1e-12)
+    npt.assert_allclose(ne, n1, rtol=1e-12)
+
+
+def test_per_replicate_parameters_on_the_nd_path():
+    """theta per replicate (BASELINE config 4's grid carried to d = 2): batched transition tables and batched likelihood
+    parameters give, replicate by replicate, the bits of the single-theta runs."""
+    from mfs_amd import sym
+    from mfs_amd.multi_dims import ss_models
+    N, Tn = 3, 40
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    pdt, _, _, gs, pdrift, pdisp, _, ppmf, _ = ss_models.prey_predator(mi)
+    sig = np.array([0.05, 0.1, 0.2])
+    off = np.array([1.0, 0.5, 1.5])
+    B = sig.shape[0]
+    ys, _ = synth.prey_predator_batch(B, Tn, pdt, seed=4)
+
+    def disp_b(s):
+        return lambda x: np.array([[s * x[0], 0.], [0., s * x[1]]], dtype=object)
+
+    def pmf_b(c):
+        return lambda y, x: stats.bernoulli_pmf(y, 1. / (1. + sym.exp(-x[0] ** 3 + c)))
+
+    per = [moments.sde_cond_moments_tme(pdrift, disp_b(s), pdt, 2) for s in sig]
+    fns = moments.batch_closures(per)
+    cm, me, ne = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf_b(off), ys, (mi, inds), gs.cms, gs.mean)
+    for b in range(B):
+        c1, m1_, n1 = filtering.moment_filter_nd_cms((per[b][1], 'multi-index'), per[b][3], pmf_b(float(off[b])), ys[b],
+                                                     (mi, inds), gs.cms, gs.mean)
+        npt.assert_array_equal(cm[b], c1)
+        npt.assert_array_equal(me[b], m1_)
+        assert ne[b] == n1
+    assert len({float(v) for v in ne}) == B
+    with pytest.raises(ValueError):      # per-replicate parameters need a replicate axis on ys
+        filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf_b(off), ys[0], (mi, inds), gs.cms, gs.mean)

@@ -1,0 +1,131 @@
+"""Filter-level `stable=True` (LDL^T completion, mfs/utils.py:495-538 through mfs/one_dim/filtering.py:77,82 and
+mfs/multi_dims/filtering.py) on the device against `oracle.moment_filter_*(..., stable=True)`:
+
+  * on well-posed input the completed factor IS the Cholesky factor: stable=True equals stable=False;
+  * an initial moment vector whose Hankel / Gram matrix has a NEGATIVE LDL^T pivot actually triggers the `eps`
+    completion (R = L diag(d < 0 ? eps : sqrt(d)), eps = 1e-8 ||G||_F, :525-538): stable=False poisons at step 0,
+    stable=True runs on and matches the oracle.
+"""
+import math
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from mfs_amd import synth
+from mfs_amd.one_dim import filtering, moments, ss_models
+from oracle import one_dim as o, models as om, tme_sympy, parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _benes(N, order=2):
+    dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+    odt, _, oic, odrift, odisp, _, opmf = om.benes_bernoulli(N)
+    dev = moments.sde_cond_moments_tme(drift, dispersion, dt, order)
+    ora = tme_sympy.sde_cond_moments_tme_1d(odrift, odisp, odt, order, 2 * N)
+    return dt, ic, pmf, dev, oic, opmf, ora
+
+
+@pytest.mark.parametrize('mode', ['raw', 'central', 'scaled'])
+def test_1d_stable_filter_matches_oracle_and_plain_filter(mode):
+    N, T, B = 5, 60, 3
+    dt, ic, pmf, dev, oic, opmf, ora = _benes(N)
+    ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=11)
+    s0 = math.sqrt(ic.variance)
+    if mode == 'raw':
+        run = lambda st: filtering.moment_filter_rms(dev[0], pmf, ic.rms, ys, stable=st)          # noqa: E731
+        ref = [o.moment_filter_rms(ora[0], opmf, oic.rms, y, stable=True) for y in ys]
+    elif mode == 'central':
+        run = lambda st: filtering.moment_filter_cms(dev[1], dev[3], pmf, ic.cms, ic.mean, ys, stable=st)   # noqa: E731
+        ref = [o.moment_filter_cms(ora[1], ora[3], opmf, oic.cms, oic.mean, y, stable=True) for y in ys]
+    else:
+        run = lambda st: filtering.moment_filter_scms(dev[2], dev[4], pmf, ic.scms, ic.mean, s0, ys, stable=st)   # noqa: E731
+        ref = [o.moment_filter_scms(ora[2], ora[4], opmf, oic.scms, oic.mean, s0, y, stable=True) for y in ys]
+    got, plain = run(True), run(False)
+    for b in range(B):
+        npt.assert_allclose(got[-1][b], ref[b][-1], rtol=1e-6)
+        assert parity.rel_err(got[0][b], ref[b][0], parity.moment_floor(ref[b][0])).max() <= 1e-6
+        for k in range(1, len(got) - 1):
+            npt.assert_allclose(got[k][b], ref[b][k], rtol=1e-6, atol=1e-9)
+    # Cholesky == completed LDL^T on positive definite input (reference tests/test_utils.py:198-209, at filter level)
+    npt.assert_allclose(got[-1], plain[-1], rtol=1e-9)
+    assert parity.rel_err(got[0], plain[0], parity.moment_floor(plain[0])).max() <= 1e-7
+
+
+def test_1d_stable_completes_an_indefinite_start():
+    """cms0 with E[(x - m)^4] < E[(x - m)^2]^2: the 3 x 3 Hankel matrix has LDL^T pivots (1, 0.3, < 0)."""
+    N, T = 3, 40
+    dt, ic, pmf, dev, oic, opmf, ora = _benes(N)
+    cms0 = np.array([1., 0., 0.3, 0.01, 0.05, 0.002])      # 0.05 < 0.3^2: not a moment sequence
+    G = cms0[np.add.outer(np.arange(N), np.arange(N))]
+    _, dpiv = o.ldl(G)
+    assert dpiv.min() < 0.                                   # the completion branch is taken at the first rule
+    ys, _ = synth.benes_bernoulli_batch(2, T, dt, seed=2)
+    m, means, nell, fn = filtering.moment_filter_cms(dev[1], dev[3], pmf, cms0, 0.1, ys, stable=True, return_first_nan=True)
+    compared = 0
+    for b in range(2):
+        r = o.moment_filter_cms(ora[1], ora[3], opmf, cms0, 0.1, ys[b], stable=True)
+        # A completed rule carries a node at ~1e13 with a negligible weight: from then on the filter effectively runs on
+        # N - 1 atoms, the next Hankel matrix is singular to rounding, and whether its last pivot lands at -1e-17 (completed
+        # again), +1e-17 or exactly 0 (singular solve: NaN in-band) is rounding luck on either side.  What the filter
+        # delivers in that regime is the NLL, the mean and the variance; the top moments are ~1e26 noise.
+        if not np.isfinite(r[2]):
+            continue
+        compared += 1
+        assert fn[b] == -1
+        npt.assert_allclose(nell[b], r[2], rtol=1e-6)
+        npt.assert_allclose(means[b], r[1], rtol=1e-6, atol=1e-9)
+        npt.assert_allclose(m[b, :, 2], r[0][:, 2], rtol=1e-6)
+        npt.assert_allclose(m[b, 3:, 3], r[0][3:, 3], rtol=1e-5, atol=1e-9)
+    assert compared >= 1
+    # without the completion the same start poisons at once, as the reference's Cholesky does
+    _, _, nell0, fn0 = filtering.moment_filter_cms(dev[1], dev[3], pmf, cms0, 0.1, ys, stable=False, return_first_nan=True)
+    assert np.all(fn0 == 0) and np.all(np.isnan(nell0))
+    r0 = o.moment_filter_cms(ora[1], ora[3], opmf, cms0, 0.1, ys[0], stable=False)
+    assert np.isnan(r0[2])
+
+
+@pytest.mark.parametrize('family', ['tme_2', 'tme_normal_2'])
+def test_nd_stable_filter(family):
+    from mfs_amd.multi_dims import filtering as fnd, moments as mnd, ss_models as snd
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+        gram_and_hankel_indices_graded_lexico
+    from oracle import multi_dims as omd
+    N, T, B = 3, 40, 2
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, pmf, _ = snd.prey_predator(mi)
+    _, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    if family == 'tme_2':
+        fns, sig = mnd.sde_cond_moments_tme(drift, disp, dt, 2), 'multi-index'
+        _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, 2, mi)
+    else:
+        fns, sig = mnd.sde_cond_moments_tme_normal(drift, disp, dt, 2, mi), 'index'
+        _, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(odrift, odisp, 2, dt, 2, mi)
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=9)
+    # well-posed start: completion == Cholesky
+    cs, ms, ns = fnd.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean, stable=True)
+    cp, mp, np_ = fnd.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean, stable=False)
+    npt.assert_allclose(ns, np_, rtol=1e-9)
+    npt.assert_allclose(ms, mp, rtol=1e-9)
+    r = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean, stable=True)
+    npt.assert_allclose(ns[0], r[2], rtol=1e-6)
+    npt.assert_allclose(ms[0], r[1], rtol=1e-6)
+    # indefinite start: shrink the fourth-order moments until the Gram matrix has a negative pivot
+    bad = gs.cms.copy()
+    bad[mi.sum(axis=1) == 4] *= 0.2
+    _, dpiv = o.ldl(bad[inds[0]])
+    assert dpiv.min() < 0.
+    cb, mb, nb, fnb = fnd.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), bad, gs.mean, stable=True,
+                                               return_first_nan=True)
+    rb = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0], (mi, inds), bad, ogs.mean, stable=True)
+    if np.isfinite(rb[2]):
+        assert fnb[0] == -1
+        npt.assert_allclose(nb[0], rb[2], rtol=1e-6)
+        npt.assert_allclose(mb[0], rb[1], rtol=1e-6)
+    else:   # the completed rule may still be too far from a distribution for the filter to continue: same fate on both sides
+        assert fnb[0] >= 0
+    _, _, n0, fn0 = fnd.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), bad, gs.mean, stable=False,
+                                             return_first_nan=True)
+    assert np.all(fn0 == 0) and np.all(np.isnan(n0))
