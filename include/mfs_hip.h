@@ -39,6 +39,11 @@ extern "C" {
 #define MFS_MODE_RAW 0
 #define MFS_MODE_CENTRAL 1
 #define MFS_MODE_SCALED 2
+/* OR-ed into `mode`: the moment vectors carry 2N + 1 entries instead of 2N.  The reference warns about an odd count and
+ * proceeds (mfs/one_dim/filtering.py:65-66): N = floor(M / 2) (mfs/one_dim/quadtures.py:122), every rule is built from
+ * the first 2N entries, and the last entry of each output row is the N-node rule's value of the order-2N moment.  m0 and
+ * out_moments then have rows of 2N + 1 doubles; the run uses the dense kernel in one launch. */
+#define MFS_MODE_ODD_TAIL 0x100
 
 /* how the transition moments E[(X_k - c)^n | X_{k-1} = x] are produced on the device */
 #define MFS_TRANS_OPERATOR 0 /* TME without closure: sum_{k<=K} Q_k(u(x)) n!/(n-k)! (x - c)^(n-k);

@@ -63,15 +63,16 @@ int check_model(const mfs_model_1d* m, int mode) {
     if (m->lik_kind < 0 || m->lik_kind > MFS_LIK_GAUSSIAN) return fail(MFS_EINVAL, "unknown lik_kind %d", m->lik_kind);
     if (m->n_lik < 1 || m->n_lik > MFS_MAX_LIK) return fail(MFS_EINVAL, "n_lik %d outside [1, %d]", m->n_lik, MFS_MAX_LIK);
     if (!m->coef || !m->lik) return fail(MFS_EINVAL, "model tables are NULL");
-    if (mode < MFS_MODE_RAW || mode > MFS_MODE_SCALED) return fail(MFS_EINVAL, "unknown mode %d", mode);
+    if ((mode & 0xff) < MFS_MODE_RAW || (mode & 0xff) > MFS_MODE_SCALED || (mode & ~(0xff | MFS_MODE_ODD_TAIL)))
+        return fail(MFS_EINVAL, "unknown mode %d", mode);
     return MFS_OK;
 }
 
 // Kernel choice.  Default: the register-resident fast path with the smallest lane group that holds the N + 1 rows of
 // the extended Hankel matrix.  stable=1 (LDL^T completion breaks the tridiagonal structure) and MFS_SOLVER=dense use
 // the LDS-tile dense path.  MFS_LANES_PER_FILTER=16|32|64 overrides the group width (experiments).
-int pick_slot(int N, int stable) {
-    bool dense = stable != 0;
+int pick_slot(int N, int stable, int odd_tail = 0) {
+    bool dense = stable != 0 || odd_tail != 0;
     if (const char* e = getenv("MFS_SOLVER")) dense = dense || (strcmp(e, "dense") == 0);
     int want = 0;
     if (const char* e = getenv("MFS_LANES_PER_FILTER")) want = atoi(e);
@@ -94,7 +95,7 @@ int pick_slot(int N, int stable) {
 
 struct mfs_plan_1d {
     mfs_model_1d model;  // device pointers inside
-    int mode, N, T, B, stable, chunk, device;
+    int mode, N, T, B, stable, chunk, device, extra;
     int slot, G, fpb, grid, lds_bytes, lds_doubles;
     bool single_wave_per_simd = false;
     double* d_coef = nullptr;
@@ -205,14 +206,17 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     if (N < 2 || N > MFS_MAX_N) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, %d]", N, MFS_MAX_N);
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (chunk < 0) return fail(MFS_EINVAL, "negative chunk");
-    const int slot = pick_slot(N, stable);
+    const int extra = (mode & MFS_MODE_ODD_TAIL) ? 1 : 0;
+    mode &= 0xff;
+    if (extra && chunk != 0 && chunk < T) return fail(MFS_EUNSUPPORTED, "an odd moment count runs in one launch (chunk = 0)");
+    const int slot = pick_slot(N, stable, extra);
     const mfs::KernelEntry& ke = mfs::g_table[N][slot];
     if (!ke.quad) return fail(MFS_EUNSUPPORTED, "no kernel compiled for N = %d", N);
     HIP_TRY(hipSetDevice(device));
 
     mfs_plan_1d* p = new mfs_plan_1d();
     p->model = *model;
-    p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device;
+    p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device; p->extra = extra;
     p->chunk = (chunk == 0 || chunk > T) ? T : chunk;
     p->slot = slot;
     p->G = ke.lanes_per_filter;
@@ -294,7 +298,7 @@ static mfs::Filter1dArgs plan_args(const mfs_plan_1d* p, const double* d_m0, int
                                     int32_t* d_out_first_nan) {
     mfs::Filter1dArgs a;
     memset(&a, 0, sizeof(a));
-    a.mode = p->mode; a.T = p->T; a.B = p->B; a.stable = p->stable;
+    a.mode = p->mode; a.T = p->T; a.B = p->B; a.stable = p->stable; a.extra = p->extra;
     a.trans_kind = p->model.trans_kind; a.umap = p->model.umap; a.n_terms = p->model.n_terms;
     a.degree = p->model.degree; a.n_rows = p->model.n_rows; a.coef_batched = p->model.coef_batched;
     a.lik_kind = p->model.lik_kind; a.n_lik = p->model.n_lik; a.lik_batched = p->model.lik_batched;
@@ -365,14 +369,16 @@ int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B, cons
                   double* out_means, double* out_scales, double* out_nell, int32_t* out_first_nan, int device,
                   void* stream) {
     if (!m0 || !out_nell || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "m0 / ys / out_nell must not be NULL");
+    const int extra = (mode & MFS_MODE_ODD_TAIL) ? 1 : 0, full_mode = mode;
+    mode &= 0xff;
     if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
     if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
-    const size_t M2 = 2 * (size_t)N, nb = m0_batched ? B : 1;
+    const size_t M2 = 2 * (size_t)N + extra, nb = m0_batched ? B : 1;     // doubles per moment row
     const size_t mom_bytes = out_moments ? (size_t)B * T * M2 * 8 : 0;
-    const int nchunks = (B > 0 && T > 0) ? host_chunks(mom_bytes, T) : 1;
+    const int nchunks = (B > 0 && T > 0 && !extra) ? host_chunks(mom_bytes, T) : 1;
     const int chunk = (nchunks > 1) ? (T + nchunks - 1) / nchunks : 0;
     mfs_plan_1d* p = nullptr;
-    if (int rc = mfs_plan_1d_create(&p, model, mode, N, T, B, stable, chunk, device)) return rc;
+    if (int rc = mfs_plan_1d_create(&p, model, full_mode, N, T, B, stable, chunk, device)) return rc;
     struct PlanGuard { mfs_plan_1d* p; ~PlanGuard() { destroy_plan_1d(p, true); } } guard{p};  // (every exit below is quiesced)
     if (B == 0) return MFS_OK;
 

@@ -26,6 +26,7 @@ namespace mfs {
 
 struct Filter1dArgs {
     int mode, T, B, stable;
+    int extra;   // 1: the moment vectors carry 2N + 1 entries (dense path only; the order-2N moment is an output, never an input)
     int t_begin, t_end;
     // model
     int trans_kind, umap, n_terms, degree, n_rows, coef_batched, lik_kind, n_lik, lik_batched;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_kernel(const Filter1dArg
     double mean = 0.0, scale = 1.0, nell = 0.0;
     int first_nan = -1;
     if (a.t_begin == 0) {
-        const double* src = a.m0 + (a.m0_batched ? (size_t)b * M2 : 0);
+        const double* src = a.m0 + (a.m0_batched ? (size_t)b * (M2 + a.extra) : 0);
         for (int n = l; n < M2; n += G) mom[n] = src[n];
         if (a.mode != MFS_MODE_RAW) mean = a.mean0[a.m0_batched ? b : 0];
         if (a.mode == MFS_MODE_SCALED) scale = a.scale0[a.m0_batched ? b : 0];
@@ -453,6 +454,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_kernel(const Filter1dArg
     const double* yrow = a.ys + (size_t)b * a.T;
     bool dead = (first_nan >= 0);
     const double qnan = __builtin_nan("");
+    // An odd number of moments (the reference warns and proceeds, mfs/one_dim/filtering.py:65-66): N = floor(M / 2)
+    // (mfs/one_dim/quadtures.py:122), the rules are built from the first 2N moments, and the order-2N entry of every step is
+    // the N-node rule's value of that moment -- computed and carried upstream, but never read by a quadrature.
+    double tail = 0.0;
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
         const double y = yrow[t];
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_kernel(const Filter1dArg
                             TAB[i * M2 + n] = p;
                             p *= dx;
                         }
+                        if (a.extra) S[L::oV0 + i] = p;      // wl dx^(2N): the first eigenvector row is free after the quadrature
                     }
                     nell -= log(py);
                 }
@@ -518,6 +524,11 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_kernel(const Filter1dArg
                     mom[n] = acc;
                     bad |= !finite(acc);
                 }
+                if (a.extra && half == 1) {
+                    double acc = 0.0;
+                    for (int i = 0; i < N; ++i) acc += S[L::oV0 + i];
+                    tail = acc / py;
+                }
                 wave_sync();
             }
             bad |= (int)(!finite(nell) || !finite(mean) || !finite(scale));
@@ -526,13 +537,14 @@ __global__ __launch_bounds__(WPB * 64, 2) void filter1d_kernel(const Filter1dArg
         } else {
             // NaN-poisoned replicate: the reference keeps emitting NaN for every later step
             for (int n = l; n < M2; n += G) mom[n] = qnan;
-            mean = qnan; scale = qnan; nell = qnan;
+            mean = qnan; scale = qnan; nell = qnan; tail = qnan;
             wave_sync();
         }
         // ---- stream the step's results to HBM: 2N contiguous doubles per filter (+ mean, scale)
         if (a.out_mom) {
-            double* dst = a.out_mom + ((size_t)b * a.T + t) * M2;
+            double* dst = a.out_mom + ((size_t)b * a.T + t) * (M2 + a.extra);
             for (int n = l; n < M2; n += G) dst[n] = mom[n];
+            if (a.extra && l == 0) dst[M2] = dead ? qnan : tail;
         }
         if (l == 0) {
             if (a.out_mean) a.out_mean[(size_t)b * a.T + t] = mean;

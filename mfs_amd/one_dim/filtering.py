@@ -134,8 +134,9 @@ def _prep_inputs(ms0, mean0, scale0, ys, tables, lik):
         raise ValueError(f'initial moments must have shape (2N,) or ({B}, 2N), got {ms0.shape}')
     num_moments = ms0.shape[-1]
     if num_moments % 2 != 0:
-        warnings.warn(f'The order of moments {num_moments - 1} is not odd.')  # mfs/one_dim/filtering.py:65-66
-        raise ValueError('an odd number of moments cannot form the N x N Hankel pair; pass 2N moments')
+        # the reference warns and proceeds (mfs/one_dim/filtering.py:65-66) with N = floor(M / 2)
+        # (mfs/one_dim/quadtures.py:122): the last entry is carried along, computed by the N-node rule, never read
+        warnings.warn(f'The order of moments {num_moments - 1} is not odd.')
     batched = ms0.ndim == 2
     nb = B if batched else 1
 
@@ -159,14 +160,16 @@ def _run(mode, tables, lik, ms0, mean0, scale0, ys, stable, device=0, want_first
     if not 2 <= N <= _lib.MAX_N:
         raise ValueError(f'N = {N} outside the supported range [2, {_lib.MAX_N}]')
     model, keep = build_model_struct(tables, lik, B)
+    odd_tail = ms0.shape[-1] - 2 * N           # 1 for an odd moment count
     # results land in page-locked memory from the library's pool (PCIe-rate copies; MFS_PINNED_OUTPUTS=0 disables)
-    out_m = _lib.pinned_empty((B, T, 2 * N), device=device)
+    out_m = _lib.pinned_empty((B, T, 2 * N + odd_tail), device=device)
     out_mean = _lib.pinned_empty((B, T), device=device) if mode != 'raw' else None
     out_scale = _lib.pinned_empty((B, T), device=device) if mode == 'scaled' else None
     out_nell = np.empty((B,))
     out_fn = np.empty((B,), dtype=np.int32)
     L = _lib.lib()
-    _lib.check(L.mfs_filter_1d(C.byref(model), _lib.MODE[mode], N, T, B, _lib.ptr(ms0), int(batched),
+    _lib.check(L.mfs_filter_1d(C.byref(model), _lib.MODE[mode] | (_lib.MODE_ODD_TAIL if odd_tail else 0), N, T, B,
+                               _lib.ptr(ms0), int(batched),
                                _lib.ptr(mean0), _lib.ptr(scale0), _lib.ptr(ys2), int(bool(stable)),
                                _lib.ptr(out_m), _lib.ptr(out_mean), _lib.ptr(out_scale), _lib.ptr(out_nell),
                                _lib.ptr(out_fn), device, None))

@@ -175,8 +175,12 @@ def test_host_moment_utilities_match_oracle():
 
 
 def test_odd_moment_count_warns_like_the_reference():
+    """mfs/one_dim/filtering.py:65-66 warns and proceeds; so does the host side (the run itself needs a GPU: the device
+    half of this is tests/test_gpu_parity_1d.py::test_odd_moment_count_proceeds_like_the_reference)."""
     dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(3)
     r, *_ = moments.sde_cond_moments_tme(drift, dispersion, dt, 2)
+    tables, lik = filtering.trace_model('raw', r, None, pmf)
     with pytest.warns(UserWarning, match='not odd'):
-        with pytest.raises(ValueError):
-            filtering.moment_filter_rms(r, pmf, ic.rms[:5], np.zeros(4))
+        ys2, squeeze, B, T, ms0, N, batched, mean0, scale0 = filtering._prep_inputs(ic.rms[:5], None, None, np.zeros(4),
+                                                                                    tables, lik)
+    assert N == 2 and ms0.shape == (5,) and squeeze and (B, T) == (1, 4)

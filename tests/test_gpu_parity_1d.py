@@ -375,3 +375,37 @@ def test_register_budget_builds_agree_bitwise(N):
         assert np.array_equal(nell_l[sl], nell_s, equal_nan=True)
         assert np.array_equal(me_l[sl], me_s, equal_nan=True)
         assert np.array_equal(cm_l[sl], cm_s, equal_nan=True)
+
+
+@pytest.mark.parametrize('mode', ['raw', 'central', 'scaled'])
+def test_odd_moment_count_proceeds_like_the_reference(mode):
+    """An odd number of moments: the reference warns and proceeds (mfs/one_dim/filtering.py:65-66) with
+    N = floor(M / 2) (mfs/one_dim/quadtures.py:122).  The first 2N columns are the even-count filter's, the last one is
+    the N-node rule's order-2N moment, as in the oracle."""
+    N, T, B = 4, 40, 3
+    dt, ic9, pmf, dev, oic9, opmf, ora = _benes(N, 2)
+    # 2N + 1 = 9 initial moments of the same mixture
+    from mfs_amd.utils import GaussianSum1D
+    big = GaussianSum1D.new(means=[-0.5, 0.5], variances=[0.05, 0.05], weights=[0.5, 0.5], N=N + 1)
+    ora9 = tme_sympy.sde_cond_moments_tme_1d(om.benes_bernoulli(N)[3], om.benes_bernoulli(N)[4], dt, 2, 2 * N + 1)
+    ys, _ = synth.benes_bernoulli_batch(B, T, dt, seed=31)
+    s0 = math.sqrt(big.variance)
+    with pytest.warns(UserWarning, match='not odd'):
+        if mode == 'raw':
+            got = filtering.moment_filter_rms(dev[0], pmf, big.rms[:9], ys)
+            even = filtering.moment_filter_rms(dev[0], pmf, big.rms[:8], ys)
+            ref = [o.moment_filter_rms(ora9[0], opmf, big.rms[:9], y) for y in ys]
+        elif mode == 'central':
+            got = filtering.moment_filter_cms(dev[1], dev[3], pmf, big.cms[:9], big.mean, ys)
+            even = filtering.moment_filter_cms(dev[1], dev[3], pmf, big.cms[:8], big.mean, ys)
+            ref = [o.moment_filter_cms(ora9[1], ora9[3], opmf, big.cms[:9], big.mean, y) for y in ys]
+        else:
+            got = filtering.moment_filter_scms(dev[2], dev[4], pmf, big.scms[:9], big.mean, s0, ys)
+            even = filtering.moment_filter_scms(dev[2], dev[4], pmf, big.scms[:8], big.mean, s0, ys)
+            ref = [o.moment_filter_scms(ora9[2], ora9[4], opmf, big.scms[:9], big.mean, s0, y) for y in ys]
+    assert got[0].shape == (B, T, 9)
+    npt.assert_allclose(got[-1], even[-1], rtol=1e-9)                      # the extra entry never feeds back
+    npt.assert_allclose(got[0][..., :8], even[0], rtol=1e-7, atol=1e-12)
+    for b in range(B):
+        npt.assert_allclose(got[-1][b], ref[b][-1], rtol=RTOL)
+        _assert_moments(got[0][b], ref[b][0])
