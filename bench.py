@@ -568,11 +568,17 @@ def cpu_baseline_nd(args, w, res):
     if w.d_mom is not None and w.mode == 'central':
         dev_m = w.d_mom.to_array((w.B, T, w.z))[0, :steps2]
         dev_mean = w.d_means.to_array((w.B, T, 2))[0, :steps2]
+        deg = mi.sum(axis=1)
+        e = parity.rel_err(dev_m, ref[0], parity.natural_magnitude_nd(ref[0], mi))[:, deg >= 2]
         out['max_rel_err_vs_device'] = {
+            'definition': 'relative error |device - cpu| / max(|cpu|, 1e-2 prod_k sd_k^n_k); moments of total degree >= 2',
             'steps_compared': steps2,
             'means': parity.quantity_errors(dev_mean, ref[1]),
-            'moments_all_orders_scaled': parity.quantity_errors(dev_m, ref[0], parity.moment_floor(ref[0])),
-            'moments_by_multi_index_max': parity.moment_errors_by_order(dev_m[None], ref[0][None])}
+            'variances': parity.quantity_errors(dev_m[:, [5, 3]], ref[0][:, [5, 3]]),
+            'moments_all_degrees': {'max': float(e.max()), 'p99': float(np.quantile(e, .99)), 'p50': float(np.quantile(e, .5)),
+                                    'n': int(e.size)},
+            'moments_max_by_total_degree': {int(dg): float(e[:, deg[deg >= 2] == dg].max())
+                                            for dg in range(2, int(deg.max()) + 1)}}
     if steps2 == T:
         out['nll_rel_diff_vs_device'] = float(abs(ref[2] - res['nell'][0]) / abs(ref[2]))
     return out
@@ -650,7 +656,40 @@ def cpu_baseline(args, w, res):
     if mode == 'scaled' and w.d_scales is not None:
         err['scale'] = parity.quantity_errors(w.d_scales.to_array((w.B, T))[:nb], cscales)
     out['max_rel_err_vs_device'] = err
+    exact = exact_arithmetic_errors(w, cm, cmeans, cnell, nb)
+    if exact:
+        out['max_rel_err_vs_exact_arithmetic'] = exact
     return out
+
+
+def exact_arithmetic_errors(w, cm, cmeans, cnell, nb):
+    """Device and C port against the 80-digit trajectories of tests/golden/filter_cfg2_exact_T1000.npz (the reference's
+    algorithm without rounding, oracle/exact_mp.py) on the replicates the fixture holds -- the benchmark batch's first 8.
+    Two fp64 implementations can only be compared with each other up to their own errors; this is each one's distance from
+    the truth, over the filter-steps where it is finite."""
+    from oracle import parity
+    path = os.path.join(ROOT, 'tests', 'golden', 'filter_cfg2_exact_T1000.npz')
+    if w.name != DEFAULT_WORKLOAD or not w.full_size or w.d_mom is None or not os.path.exists(path):
+        return None
+    e = np.load(path)
+    B, T = int(e['B']), int(e['T'])
+    if nb < B or T != w.T or not np.array_equal(np.packbits(w.ys[:B].astype(np.uint8), axis=1), e['ys_bits']):
+        return None
+    steps = e['moment_steps']
+    dm = w.d_mom.to_array((w.B, T, 2 * w.N))[:B]
+    dmeans = w.d_means.to_array((w.B, T))[:B]
+    sd = np.sqrt(e['central_variances'])
+    floor = parity.moment_floor(e['central_moments'])
+
+    def score(mom, means):
+        with np.errstate(all='ignore'):
+            return {'mean': parity.quantity_errors(means, e['central_means'], np.maximum(sd, 1e-300)),
+                    'variance': parity.quantity_errors(mom[..., 2], e['central_variances']),
+                    'moments_all_orders': parity.quantity_errors(mom[:, steps], e['central_moments'], floor),
+                    'moments_by_order_max': parity.moment_errors_by_order(mom[:, steps], e['central_moments']),
+                    'first_non_finite_step': [int(v) for v in parity.first_nan_steps(means[..., None], T)]}
+    return {'fixture': 'tests/golden/filter_cfg2_exact_T1000.npz (80-digit mpmath, 8 replicates x 1000 steps)',
+            'device': score(dm, dmeans), 'c_port': score(cm[:B], cmeans[:B])}
 
 
 if __name__ == '__main__':

@@ -28,6 +28,15 @@ def moment_floor(ref):
     return neighbour * 1e-3 + 1e-300
 
 
+def natural_magnitude_nd(ref, multi_indices):
+    """(..., z) floor for N-D central moments: 1e-2 x prod_k sd_k^{n_k} with sd_k from the reference's own second moments
+    (graded-lex d = 2: (2, 0) is entry 5, (0, 2) entry 3).  First-order central moments and odd moments of near-symmetric
+    laws are rounding noise around zero; a pure relative error is meaningless there."""
+    ref, mi = np.asarray(ref), np.asarray(multi_indices)
+    sd = np.sqrt(np.stack([np.abs(ref[..., 5]), np.abs(ref[..., 3])], axis=-1))
+    return 1e-2 * np.prod(sd[..., None, :] ** mi, axis=-1) + 1e-300
+
+
 def rel_err(got, ref, floor=0.):
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     with np.errstate(all='ignore'):

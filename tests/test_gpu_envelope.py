@@ -125,9 +125,12 @@ def test_device_against_exact_arithmetic_full_length(golden_dir):
     T, B = int(e['T']), int(e['B'])
     ys = ys_full[:B, :T]
     npt.assert_array_equal(np.packbits(ys.astype(np.uint8), axis=1), e['ys_bits'])
-    assert np.all(e['central_first_nan'] == -1)
+    # (over 1000 steps cond(Hankel) outgrows even 80 digits for some replicates -- 1e80 where fp64 gave up at 1e16 hundreds
+    #  of steps earlier; the arbiter's own horizon is recorded in the fixture and every fp64 run ends well before it)
+    horizon = np.where(e['central_first_nan'] >= 0, e['central_first_nan'], T)
     steps = e['moment_steps']
     m, means, second, nell, fn = _device('central', ic, f, pmf, ys)
+    assert np.all(np.where(fn >= 0, fn, T) <= horizon)
     dev = _errors(m[:, steps], means, second, nell, e, 'central')
     cm, cmeans, csecond, cnell = _cport('central', N, oic, tab, ys)
     cpo = _errors(cm[:, steps], cmeans, csecond, cnell, e, 'central')
