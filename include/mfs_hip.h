@@ -180,6 +180,25 @@ int mfs_plan_1d_geometry(const mfs_plan_1d* plan, int* lanes_per_filter, int* fi
                          int* lds_bytes_per_block);
 
 /*
+ * ---- negative log-likelihood and its gradient, forward mode inside the time loop ------------------------------------
+ * Replaces what dardel/parameter_estimation/mf.py:37-54,70-73 obtains by differentiating obj_func (moment_filter_cms
+ * under jax.jit) through the lax.scan with JAX autodiff for jaxopt.ScipyMinimize(L-BFGS-B): the filter's state -- moments,
+ * mean, scale, nell -- is carried as dual numbers (value + n_par tangents) through every Cholesky pivot, eigenvalue,
+ * weight and quadrature sum (mfs_amd/csrc/filter1d_grad.hpp); no reverse pass.
+ *
+ *   model       the value tables, as for mfs_filter_1d (coef_batched / lik_batched: one parameter point per replicate)
+ *   dcoef       d coef / d theta_p: [n_par][n_rows][degree + 1], or [B][n_par][n_rows][degree + 1] when coef_batched
+ *   dlik        d lik / d theta_p:  [n_par][n_lik], or [B][n_par][n_lik] when lik_batched
+ *   n_par       1 .. 4;  N  2 .. 10;  m0, mean0, scale0, ys as for mfs_filter_1d (the initial law does not depend on theta)
+ *   out_nell    [B];  out_grad [B][n_par] = d nell / d theta_p;  out_first_nan [B] or NULL.  Host pointers.
+ * A replicate that NaN-poisons returns NaN in both, as the reference's objective would.
+ */
+int mfs_filter_1d_grad(const mfs_model_1d* model, const double* dcoef, const double* dlik, int n_par, int mode, int N,
+                       int T, int B, const double* m0, int m0_batched, const double* mean0, const double* scale0,
+                       const double* ys, double* out_nell, double* out_grad, int32_t* out_first_nan, int device,
+                       void* stream);
+
+/*
  * ---- quadrature only -----------------------------------------------------------------------------------------
  * Replaces moment_quadrature (mfs/one_dim/quadtures.py:83-133) for B moment vectors: ms [B][2N], mean/scale [B] or
  * NULL (0 / 1), out weights/nodes [B][N].  Host pointers.  Used by the parity tests to check the Cholesky /

@@ -79,6 +79,8 @@ _SIGNATURES = [
     ('mfs_event_elapsed_ms', _i, [_vp, _vp, C.POINTER(C.c_float)]),
     ('mfs_filter_1d', _i, [C.POINTER(MfsModel1d), _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i,
                            _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    ('mfs_filter_1d_grad', _i, [C.POINTER(MfsModel1d), _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i, _vp]),
     ('mfs_plan_1d_create', _i, [_vpp, C.POINTER(MfsModel1d), _i, _i, _i, _i, _i, _i, _i]),
     ('mfs_plan_1d_run', _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ('mfs_plan_1d_destroy', _i, [_vp]),

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "filternd_kernel.hpp"
+#include "filter1d_grad.hpp"
 #include "pool.hpp"
 
 namespace mfs {
@@ -24,6 +25,7 @@ using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t
 struct NdEntry { FilterNdLaunch launch, launch_gauss; int S, Z, lds_bytes; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
 hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s);
+extern Filter1dGradLaunch g_grad_table[11][5];  // filter1d_grad_inst.hip: [N <= 10][P <= 4]
 }
 
 namespace {
@@ -446,6 +448,68 @@ int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B, cons
     if (rc != MFS_OK) return rc;
     if (e == hipSuccess) e = (e1 != hipSuccess) ? e1 : e2;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_1d: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
+int mfs_filter_1d_grad(const mfs_model_1d* model, const double* dcoef, const double* dlik, int n_par, int mode, int N,
+                       int T, int B, const double* m0, int m0_batched, const double* mean0, const double* scale0,
+                       const double* ys, double* out_nell, double* out_grad, int32_t* out_first_nan, int device,
+                       void* stream) {
+    if (int rc = check_model(model, mode)) return rc;
+    if (mode & MFS_MODE_ODD_TAIL) return fail(MFS_EUNSUPPORTED, "the gradient entry point takes 2N moments");
+    if (n_par < 1 || n_par > 4) return fail(MFS_EUNSUPPORTED, "n_par = %d outside [1, 4]", n_par);
+    if (N < 2 || N > 10) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, 10] for the gradient kernel", N);
+    if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
+    if (!dcoef || !dlik || !m0 || !out_nell || !out_grad || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "NULL buffer");
+    if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
+    if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
+    if (B == 0) return MFS_OK;
+    mfs::Filter1dGradLaunch launch = mfs::g_grad_table[N][n_par];
+    if (!launch) return fail(MFS_EUNSUPPORTED, "no gradient kernel compiled for N = %d, n_par = %d", N, n_par);
+    HIP_TRY(hipSetDevice(device));
+    mfs::Lease lease(device);
+    mfs::CallContext* cx = nullptr;
+    hipError_t e = lease.context(&cx);
+    if (e != hipSuccess) return fail(MFS_EHIP, "mfs_filter_1d_grad: %s", hipGetErrorString(e));
+    hipStream_t s = stream ? (hipStream_t)stream : cx->compute;
+    const size_t J1 = (size_t)model->degree + 1, ncoef = (size_t)model->n_rows * J1;
+    const size_t nbc = model->coef_batched ? B : 1, nbl = model->lik_batched ? B : 1, nb = m0_batched ? B : 1, M2 = 2 * (size_t)N;
+    double *d_coef = nullptr, *d_dcoef = nullptr, *d_lik = nullptr, *d_dlik = nullptr, *d_m0 = nullptr, *d_mean0 = nullptr,
+           *d_scale0 = nullptr, *d_ys = nullptr, *d_nell = nullptr, *d_grad = nullptr;
+    int32_t* d_fn = nullptr;
+    auto alloc = [&](auto** d, size_t bytes) { if (e == hipSuccess) e = lease.device_block(d, bytes); };
+    auto h2d = [&](void* d, const void* h, size_t bytes) {
+        if (e == hipSuccess && bytes && h) e = hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s);
+    };
+    alloc(&d_coef, nbc * ncoef * 8); alloc(&d_dcoef, nbc * n_par * ncoef * 8);
+    alloc(&d_lik, nbl * model->n_lik * 8); alloc(&d_dlik, nbl * n_par * model->n_lik * 8);
+    alloc(&d_m0, nb * M2 * 8); alloc(&d_mean0, nb * 8); alloc(&d_scale0, nb * 8);
+    alloc(&d_ys, (size_t)B * T * 8); alloc(&d_nell, (size_t)B * 8); alloc(&d_grad, (size_t)B * n_par * 8);
+    alloc(&d_fn, (size_t)B * 4);
+    h2d(d_coef, model->coef, nbc * ncoef * 8); h2d(d_dcoef, dcoef, nbc * n_par * ncoef * 8);
+    h2d(d_lik, model->lik, nbl * model->n_lik * 8); h2d(d_dlik, dlik, nbl * n_par * model->n_lik * 8);
+    h2d(d_m0, m0, nb * M2 * 8); h2d(d_mean0, mean0, nb * 8); h2d(d_scale0, scale0, nb * 8);
+    h2d(d_ys, ys, (size_t)B * T * 8);
+    if (e == hipSuccess) {
+        mfs::Filter1dGradArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        mfs::Filter1dArgs& a = ga.f;
+        a.mode = mode; a.T = T; a.B = B; a.t_begin = 0; a.t_end = T;
+        a.trans_kind = model->trans_kind; a.umap = model->umap; a.n_terms = model->n_terms; a.degree = model->degree;
+        a.n_rows = model->n_rows; a.coef_batched = model->coef_batched; a.lik_kind = model->lik_kind; a.n_lik = model->n_lik;
+        a.lik_batched = model->lik_batched; a.mean_x_coef = model->mean_x_coef; a.coef = d_coef; a.lik = d_lik;
+        a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
+        a.out_nell = d_nell; a.out_first_nan = d_fn;
+        ga.n_par = n_par; ga.dcoef = d_dcoef; ga.dlik = d_dlik; ga.out_grad = d_grad;
+        e = launch(ga, (B + 3) / 4, s);
+    }
+    auto d2h = [&](void* h, const void* d, size_t bytes) {
+        if (e == hipSuccess && h && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);
+    };
+    d2h(out_nell, d_nell, (size_t)B * 8); d2h(out_grad, d_grad, (size_t)B * n_par * 8); d2h(out_first_nan, d_fn, (size_t)B * 4);
+    const hipError_t es = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = es;
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_1d_grad: %s", hipGetErrorString(e));
     return MFS_OK;
 }
 

@@ -1,0 +1,422 @@
+// filter1d_grad.hpp -- forward-mode derivative of the 1-D moment filter's negative log-likelihood with respect to model
+// parameters, propagated INSIDE the time-step loop.
+//
+// Reference: dardel/parameter_estimation/mf.py:37-54,70-73 -- obj_func(params, ys) runs moment_filter_cms and
+// jaxopt.ScipyMinimize(L-BFGS-B) differentiates through the lax.scan by JAX autodiff.  Here every quantity of the scan
+// body (mfs/one_dim/filtering.py:73-86, 140-158, 217-237) is a dual number (value, P tangents) and the whole recursion
+// runs on them: no reverse pass, no tape, P extra "lanes of state" per filter.
+//
+// Per rule, with the moments m_n as duals:
+//   recurrence coefficients  the Chebyshev algorithm on the moments,
+//                                sigma_{k,l} = sigma_{k-1,l+1} - alpha_{k-1} sigma_{k-1,l} - beta_{k-1} sigma_{k-2,l},
+//                            whose diagonal sigma_{k,k} is the k-th pivot of the Hankel Cholesky (quadtures.py:127) and
+//                            alpha_k = sigma_{k,k+1}/sigma_{k,k} - sigma_{k-1,k}/sigma_{k-1,k-1}, beta_k = sigma_{k,k}/sigma_{k-1,k-1}
+//                            the entries of the Jacobi matrix K = R^-1 H R^-T (:128-131).  O(N^2) dual operations, done
+//                            redundantly by every lane (no cross-lane traffic); a pivot that is not > 0 poisons, as upstream.
+//   eigenvalues              lane k finds the k-th root of the monic p_N by Sturm bisection + Newton polish in plain fp64,
+//                            then ONE dual evaluation of the three-term recurrence at it gives the tangent by the implicit
+//                            function theorem, d lambda = -(d_theta p_N)(lambda) / p_N'(lambda)
+//   weights                  w_k = 1 / sum_j p_j(lambda_k)^2 / h_j (h_j = beta_0 ... beta_j), evaluated on duals (= V[0,k]^2, :133)
+// Prediction and update are the filter's own sums with dual nodes, weights and model tables (value tables + tangent tables
+// d coef / d theta_p supplied by the host tracer); exp / log / tanh / sqrt carry their derivatives.
+//
+// Mapping: one filter per 16-lane group (N <= 15), lane = node; group sums by shuffles.  This kernel serves optimiser
+// loops (a few to a few thousand filters per launch), not the throughput benchmark.
+#pragma once
+#include "filter1d_kernel.hpp"
+
+namespace mfs {
+
+template <int P>
+struct Dual {
+    double v;
+    double d[P];
+};
+
+template <int P> __device__ __forceinline__ Dual<P> dconst(const double v) {
+    Dual<P> r; r.v = v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = 0.0;
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> operator+(const Dual<P>& a, const Dual<P>& b) {
+    Dual<P> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = a.d[p] + b.d[p];
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> operator-(const Dual<P>& a, const Dual<P>& b) {
+    Dual<P> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = a.d[p] - b.d[p];
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> operator-(const Dual<P>& a) {
+    Dual<P> r; r.v = -a.v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = -a.d[p];
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> operator*(const Dual<P>& a, const Dual<P>& b) {
+    Dual<P> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = fma(a.v, b.d[p], a.d[p] * b.v);
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> operator*(const double a, const Dual<P>& b) {
+    Dual<P> r; r.v = a * b.v;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = a * b.d[p];
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> operator+(const Dual<P>& a, const double b) { Dual<P> r = a; r.v += b; return r; }
+template <int P> __device__ __forceinline__ Dual<P> operator-(const Dual<P>& a, const double b) { Dual<P> r = a; r.v -= b; return r; }
+template <int P> __device__ __forceinline__ Dual<P> operator/(const Dual<P>& a, const Dual<P>& b) {
+    const double ib = 1.0 / b.v;
+    Dual<P> r; r.v = a.v * ib;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = (a.d[p] - r.v * b.d[p]) * ib;
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> drecip(const Dual<P>& b) {
+    const double ib = 1.0 / b.v;
+    Dual<P> r; r.v = ib;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = -ib * ib * b.d[p];
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> dchain(const Dual<P>& a, const double f, const double fp) {   // f(a), f'(a)
+    Dual<P> r; r.v = f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r.d[p] = fp * a.d[p];
+    return r;
+}
+template <int P> __device__ __forceinline__ Dual<P> dexp(const Dual<P>& a) { const double e = exp(a.v); return dchain(a, e, e); }
+template <int P> __device__ __forceinline__ Dual<P> dlog(const Dual<P>& a) { return dchain(a, log(a.v), 1.0 / a.v); }
+template <int P> __device__ __forceinline__ Dual<P> dsqrt(const Dual<P>& a) { const double s = sqrt(a.v); return dchain(a, s, 0.5 / s); }
+template <int P> __device__ __forceinline__ Dual<P> dtanh(const Dual<P>& a) { const double t = tanh(a.v); return dchain(a, t, 1.0 - t * t); }
+
+template <int P, int G>
+__device__ __forceinline__ Dual<P> dgroup_sum(Dual<P> a) {
+    a.v = group_sum<G>(a.v);
+#pragma unroll
+    for (int p = 0; p < P; ++p) a.d[p] = group_sum<G>(a.d[p]);
+    return a;
+}
+
+struct Filter1dGradArgs {
+    Filter1dArgs f;          // the plain filter's arguments (model tables, inputs; out_mom / out_mean unused)
+    int n_par;               // P
+    const double* dcoef;     // [P][n_rows][degree + 1] (or [B][P][...] when coef_batched): d coef / d theta_p
+    const double* dlik;      // [P][n_lik] (or [B][P][n_lik]): d (likelihood parameters) / d theta_p
+    double* out_grad;        // [B][P]: d nell / d theta_p
+};
+
+// polynomial with dual coefficients at a dual argument
+template <int P>
+__device__ __forceinline__ Dual<P> dhorner(const double* __restrict__ c, const double* __restrict__ dc, const int stride_p,
+                                           const int degree, const Dual<P>& u) {
+    Dual<P> acc;
+    acc.v = c[degree];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc.d[p] = dc[p * stride_p + degree];
+    for (int j = degree - 1; j >= 0; --j) {
+        Dual<P> cj;
+        cj.v = c[j];
+#pragma unroll
+        for (int p = 0; p < P; ++p) cj.d[p] = dc[p * stride_p + j];
+        acc = acc * u + cj;
+    }
+    return acc;
+}
+
+template <int P>
+__device__ __forceinline__ Dual<P> dlikelihood(const int kind, const double* __restrict__ lp, const double* __restrict__ dlp,
+                                               const int n_lik, const double y, const Dual<P>& x) {
+    auto par = [&](int i) {
+        Dual<P> r; r.v = lp[i];
+#pragma unroll
+        for (int p = 0; p < P; ++p) r.d[p] = dlp[p * n_lik + i];
+        return r;
+    };
+    if (kind == MFS_LIK_BERNOULLI_LOGISTIC) {
+        Dual<P> z = par(0);
+        Dual<P> xp = x;
+        for (int i = 1; i < 4; ++i) { if (i < n_lik) z = z + par(i) * xp; xp = xp * x; }
+        const Dual<P> pr = drecip(dexp(-z) + 1.0);
+        return (y > 0.5) ? pr : (-pr + 1.0);
+    } else if (kind == MFS_LIK_POISSON_SOFTPLUS) {
+        const Dual<P> rate = dlog(dexp(par(0) * x) + 1.0);
+        return dexp(y * dlog(rate) - rate - log_factorial(y));
+    } else {
+        const Dual<P> r = -(par(0) * x + par(1)) + y;
+        const Dual<P> var = par(2);
+        return dexp(-0.5 * (r * r / var)) * drecip(dsqrt(6.283185307179586476925 * var));
+    }
+}
+
+// Gauss rule on duals: every lane runs the Chebyshev algorithm on the 2N dual moments in LDS; lane l < N then owns root l.
+template <int N, int G, int P>
+__device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /* [1 + P][2N] */, const int l,
+                                                const Dual<P>& mean, const Dual<P>& scale, Dual<P>& x_out, Dual<P>& w_out) {
+    constexpr int M2 = 2 * N;
+    Dual<P> alpha[N], beta[N];          // beta[0] = m_0
+    bool poisoned = false;
+    {
+        Dual<P> prev[M2], cur[M2], piv_prev, sub_prev_over_piv;
+#pragma unroll
+        for (int n = 0; n < M2; ++n) {
+            cur[n].v = mom[n];
+#pragma unroll
+            for (int p = 0; p < P; ++p) cur[n].d[p] = mom[(1 + p) * M2 + n];
+            prev[n] = dconst<P>(0.0);
+        }
+        beta[0] = cur[0];
+        poisoned |= !(cur[0].v > 0.0);
+        alpha[0] = cur[1] / cur[0];
+        piv_prev = cur[0];
+        sub_prev_over_piv = alpha[0];
+        // sigma_{k, l}, l = k .. 2N - 1 - k, from rows k - 1 (cur) and k - 2 (prev), overwriting in place
+#pragma unroll
+        for (int k = 1; k < N; ++k) {
+#pragma unroll
+            for (int ll = k; ll < M2 - k; ++ll) {
+                const Dual<P> s = cur[ll + 1] - alpha[k - 1] * cur[ll] - ((k >= 2) ? beta[k - 1] * prev[ll] : dconst<P>(0.0));
+                prev[ll] = cur[ll];      // row k - 1 entry l, needed as "k - 2" in the next round
+                cur[ll] = s;
+            }
+            // (entries below k of cur / prev are stale and never read again)
+            const Dual<P> piv = cur[k];
+            poisoned |= !(piv.v > 0.0);
+            beta[k] = piv / piv_prev;
+            const Dual<P> ratio = cur[k + 1] / piv;
+            alpha[k] = ratio - sub_prev_over_piv;
+            piv_prev = piv;
+            sub_prev_over_piv = ratio;
+        }
+    }
+    // NOTE on the in-place update above: cur[ll + 1] read at step ll is still row k - 1 (it is overwritten at step ll + 1),
+    // and prev[ll] read at step ll is row k - 2 (overwritten right after with row k - 1).
+    // ---- root l by Sturm bisection (plain fp64), Gershgorin interval of the symmetric tridiagonal
+    double lo = 1.79e308, hi = -1.79e308;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double r = ((j > 0) ? sqrt(fabs(beta[j].v)) : 0.0) + ((j + 1 < N) ? sqrt(fabs(beta[j + 1].v)) : 0.0);
+        lo = fmin(lo, alpha[j].v - r);
+        hi = fmax(hi, alpha[j].v + r);
+    }
+    const int k = (l < N) ? l : N - 1;
+    auto count_below = [&](const double x) {   // number of eigenvalues < x (Sturm sequence of the LDL^T pivots)
+        int cnt = 0;
+        double q = alpha[0].v - x;
+        cnt += (q < 0.0);
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            q = (alpha[j].v - x) - beta[j].v / ((q != 0.0) ? q : 1e-300);
+            cnt += (q < 0.0);
+        }
+        return cnt;
+    };
+    double a = lo, b = hi;
+    for (int it = 0; it < 64; ++it) {
+        const double mid = 0.5 * (a + b);
+        if (count_below(mid) > k) b = mid; else a = mid;
+    }
+    double lam = 0.5 * (a + b);
+    for (int it = 0; it < 3; ++it) {           // Newton polish on the monic p_N
+        double p0 = 1.0, p1 = lam - alpha[0].v, d0 = 0.0, d1 = 1.0;
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            const double pn = (lam - alpha[j].v) * p1 - beta[j].v * p0;
+            const double dn = p1 + (lam - alpha[j].v) * d1 - beta[j].v * d0;
+            p0 = p1; p1 = pn; d0 = d1; d1 = dn;
+        }
+        const double step = p1 / d1;
+        if (finite(step) && lam - step > a - (b - a) && lam - step < b + (b - a)) lam -= step;
+    }
+    // ---- tangent of the root: one dual evaluation of the recurrence at (lam, 0)
+    Dual<P> L0 = dconst<P>(lam);
+    {
+        Dual<P> p0 = dconst<P>(1.0), p1 = L0 - alpha[0];
+        double d0 = 0.0, d1 = 1.0;
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            const Dual<P> pn = (L0 - alpha[j]) * p1 - beta[j] * p0;
+            const double dn = p1.v + (lam - alpha[j].v) * d1 - beta[j].v * d0;
+            p0 = p1; p1 = pn; d0 = d1; d1 = dn;
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) L0.d[p] = -p1.d[p] / d1;
+    }
+    // ---- weight on duals: 1 / sum_j p_j(lam)^2 / h_j
+    Dual<P> w;
+    {
+        Dual<P> p0 = dconst<P>(1.0), p1 = L0 - alpha[0];
+        Dual<P> h = beta[0];
+        Dual<P> acc = drecip(h);
+#pragma unroll
+        for (int j = 1; j < N; ++j) {
+            h = h * beta[j];
+            acc = acc + p1 * p1 / h;
+            const Dual<P> pn = (L0 - alpha[j]) * p1 - beta[j] * p0;
+            p0 = p1; p1 = pn;
+        }
+        w = drecip(acc);
+    }
+    const double qnan = __builtin_nan("");
+    x_out = scale * L0 + mean;
+    w_out = (l < N) ? w : dconst<P>(0.0);
+    if (poisoned) { x_out = dconst<P>(qnan); w_out = dconst<P>(qnan); }
+    return poisoned;
+}
+
+// One filter per G-lane group.  LDS per filter: dual moments [1 + P][2N], contribution table [G][1 + P][2N].
+template <int N, int G, int P>
+__global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGradArgs ga) {
+    const Filter1dArgs& a = ga.f;
+    constexpr int M2 = 2 * N, FPW = 64 / G, DW = (1 + P) * M2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / G, l = lane - grp * G;
+    const int b = blockIdx.x * FPW + grp;
+    if (b >= a.B) return;
+    double* S = smem + (size_t)grp * (DW + G * DW + kCoefDoubles * (1 + P) + (MFS_MAX_LIK) * (1 + P));
+    double* mom = S;                              // [1 + P][2N]
+    double* TAB = S + DW;                         // [G][1 + P][2N]
+    double* coef = TAB + G * DW;                  // [n_rows][J + 1]
+    double* dcoef = coef + kCoefDoubles;          // [P][n_rows][J + 1]
+    double* lp = dcoef + kCoefDoubles * P;        // [n_lik]
+    double* dlp = lp + MFS_MAX_LIK;               // [P][n_lik]
+    const int J1 = a.degree + 1, ncoef = a.n_rows * J1;
+    {
+        const double* src = a.coef + (a.coef_batched ? (size_t)b * ncoef : 0);
+        for (int e = l; e < ncoef; e += G) coef[e] = src[e];
+        const double* dsrc = ga.dcoef + (a.coef_batched ? (size_t)b * P * ncoef : 0);
+        for (int e = l; e < P * ncoef; e += G) dcoef[e] = dsrc[e];
+        const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
+        const double* dls = ga.dlik + (a.lik_batched ? (size_t)b * P * a.n_lik : 0);
+        for (int e = l; e < a.n_lik; e += G) lp[e] = ls[e];
+        for (int e = l; e < P * a.n_lik; e += G) dlp[e] = dls[e];
+        const double* m0 = a.m0 + (a.m0_batched ? (size_t)b * M2 : 0);
+        for (int e = l; e < DW; e += G) mom[e] = (e < M2) ? m0[e] : 0.0;     // initial moments do not depend on theta
+    }
+    Dual<P> mean = dconst<P>(0.0), scale = dconst<P>(1.0), nell = dconst<P>(0.0);
+    if (a.mode != MFS_MODE_RAW) mean.v = a.mean0[a.m0_batched ? b : 0];
+    if (a.mode == MFS_MODE_SCALED) scale.v = a.scale0[a.m0_batched ? b : 0];
+    wave_sync();
+    const double* yrow = a.ys + (size_t)b * a.T;
+    bool dead = false;
+    int first_nan = -1;
+    double* myrow = TAB + l * DW;
+
+    auto store_contrib = [&](const int n, const Dual<P>& c) {
+        myrow[n] = c.v;
+#pragma unroll
+        for (int p = 0; p < P; ++p) myrow[(1 + p) * M2 + n] = c.d[p];
+    };
+    auto reduce_moments = [&](const Dual<P>& py) {
+        wave_sync();
+        const Dual<P> ipy = drecip(py);
+        bool bad = false;
+        for (int n = l; n < M2; n += G) {
+            Dual<P> acc = dconst<P>(0.0);
+            for (int i = 0; i < N; ++i) {
+                acc.v += TAB[i * DW + n];
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc.d[p] += TAB[i * DW + (1 + p) * M2 + n];
+            }
+            acc = acc * ipy;
+            mom[n] = acc.v;
+#pragma unroll
+            for (int p = 0; p < P; ++p) mom[(1 + p) * M2 + n] = acc.d[p];
+            bad |= !finite(acc.v);
+        }
+        wave_sync();
+        return bad;
+    };
+
+    for (int t = 0; t < a.T && !dead; ++t) {
+        const double y = yrow[t];
+        int bad = 0;
+        // ---- prediction
+        {
+            Dual<P> x, w;
+            bad |= dual_quadrature<N, G, P>(mom, l, mean, scale, x, w);
+            const Dual<P> u = (a.umap == MFS_U_TANH) ? dtanh(x) : x;
+            Dual<P> c = dconst<P>(0.0), inv_sc = dconst<P>(1.0);
+            if (a.trans_kind == MFS_TRANS_GAUSSIAN) {
+                const Dual<P> mu = a.mean_x_coef * x + dhorner<P>(coef, dcoef, ncoef, a.degree, u);
+                const Dual<P> var = dhorner<P>(coef + J1, dcoef + J1, ncoef, a.degree, u);
+                if (a.mode != MFS_MODE_RAW) { mean = dgroup_sum<P, G>(w * mu); c = mean; }
+                if (a.mode == MFS_MODE_SCALED) { scale = dsqrt(dgroup_sum<P, G>(w * var)); inv_sc = drecip(scale); }
+                // E_0 = 1, E_1 = m, E_n = m E_{n-1} + (n - 1) v E_{n-2}, m = mu - c
+                const Dual<P> m = mu - c;
+                Dual<P> e2 = dconst<P>(1.0), e1 = m, scn = w;
+                store_contrib(0, scn);
+                scn = scn * inv_sc;
+                store_contrib(1, scn * m);
+                for (int n = 2; n < M2; ++n) {
+                    const Dual<P> e = m * e1 + (double)(n - 1) * (var * e2);
+                    scn = scn * inv_sc;
+                    store_contrib(n, scn * e);
+                    e2 = e1; e1 = e;
+                }
+            } else {
+                // E[(X' - c)^n | x] = sum_k Q_k(u) n!/(n-k)! (x - c)^(n-k), Q_0 = 1
+                Dual<P> Q[MFS_MAX_TERMS + 1];
+                Q[0] = dconst<P>(1.0);
+                for (int k = 1; k <= MFS_MAX_TERMS; ++k)
+                    Q[k] = (k <= a.n_terms) ? dhorner<P>(coef + (k - 1) * J1, dcoef + (k - 1) * J1, ncoef, a.degree, u) : dconst<P>(0.0);
+                if (a.mode != MFS_MODE_RAW) { mean = dgroup_sum<P, G>(w * (x + Q[1])); c = mean; }
+                if (a.mode == MFS_MODE_SCALED) {
+                    const Dual<P> var = dhorner<P>(coef + a.n_terms * J1, dcoef + a.n_terms * J1, ncoef, a.degree, u);
+                    scale = dsqrt(dgroup_sum<P, G>(w * var));
+                    inv_sc = drecip(scale);
+                }
+                const Dual<P> dx = x - c;
+                Dual<P> D[MFS_MAX_TERMS + 1];
+                D[0] = dconst<P>(1.0);
+                for (int k = 1; k <= MFS_MAX_TERMS; ++k) D[k] = dconst<P>(0.0);
+                Dual<P> scn = w;
+                for (int n = 0; n < M2; ++n) {
+                    Dual<P> val = dconst<P>(0.0);
+                    for (int k = a.n_terms; k >= 0; --k) val = val + Q[k] * D[k];
+                    store_contrib(n, scn * val);
+                    scn = scn * inv_sc;
+                    for (int k = MFS_MAX_TERMS; k >= 1; --k) D[k] = dx * D[k] + (double)k * D[k - 1];
+                    D[0] = D[0] * dx;
+                }
+            }
+            bad |= reduce_moments(dconst<P>(1.0));
+        }
+        // ---- update
+        {
+            Dual<P> x, w;
+            bad |= dual_quadrature<N, G, P>(mom, l, mean, scale, x, w);
+            const Dual<P> wl = w * dlikelihood<P>(a.lik_kind, lp, dlp, a.n_lik, y, x);
+            const Dual<P> py = dgroup_sum<P, G>(wl);
+            Dual<P> c = dconst<P>(0.0), inv_sc = dconst<P>(1.0);
+            if (a.mode != MFS_MODE_RAW) { mean = dgroup_sum<P, G>(wl * x) / py; c = mean; }
+            const Dual<P> dxc = x - c;
+            if (a.mode == MFS_MODE_SCALED) { scale = dsqrt(dgroup_sum<P, G>(wl * dxc * dxc) / py); inv_sc = drecip(scale); }
+            const Dual<P> dx = dxc * inv_sc;
+            Dual<P> pw = wl;
+            for (int n = 0; n < M2; ++n) { store_contrib(n, pw); pw = pw * dx; }
+            bad |= reduce_moments(py);
+            nell = nell - dlog(py);
+        }
+        bad |= (int)(!finite(nell.v) || !finite(mean.v) || !finite(scale.v));
+        bad = group_or<G>(bad);
+        if (bad) { dead = true; first_nan = t; }
+    }
+    if (l == 0) {
+        const double qnan = __builtin_nan("");
+        a.out_nell[b] = dead ? qnan : nell.v;
+        for (int p = 0; p < P; ++p) ga.out_grad[(size_t)b * P + p] = dead ? qnan : nell.d[p];
+        if (a.out_first_nan) a.out_first_nan[b] = first_nan;
+    }
+}
+
+using Filter1dGradLaunch = hipError_t (*)(const Filter1dGradArgs&, int grid, hipStream_t);
+
+}  // namespace mfs

@@ -1,0 +1,35 @@
+// filter1d_grad_inst.hip -- instantiates the forward-mode gradient kernels (N = 2..10 quadrature nodes, P = 1..4
+// parameters; 16 lanes per filter) and registers their launchers.
+#include "filter1d_grad.hpp"
+#include "launch_util.hpp"
+
+namespace mfs {
+
+constexpr int kGradMaxN = 10, kGradMaxP = 4;
+Filter1dGradLaunch g_grad_table[kGradMaxN + 1][kGradMaxP + 1];
+
+template <int N, int P>
+int grad_lds_bytes() {
+    constexpr int G = 16, DW = (1 + P) * 2 * N;
+    return (64 / G) * (DW + G * DW + kCoefDoubles * (1 + P) + MFS_MAX_LIK * (1 + P)) * 8;
+}
+
+template <int N, int P>
+hipError_t launch_grad(const Filter1dGradArgs& a, int grid, hipStream_t s) {
+    if (hipError_t e = ensure_dynamic_lds<&filter1d_grad_kernel<N, 16, P>>(); e != hipSuccess) return e;
+    const int lds = grad_lds_bytes<N, P>();
+    hipLaunchKernelGGL((filter1d_grad_kernel<N, 16, P>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int N, int P>
+void reg_grad() {
+    g_grad_table[N][P] = &launch_grad<N, P>;
+    if constexpr (P < kGradMaxP) reg_grad<N, P + 1>();
+    else if constexpr (N < kGradMaxN) reg_grad<N + 1, 1>();
+}
+
+struct GradRegistrar { GradRegistrar() { reg_grad<2, 1>(); } };
+static GradRegistrar grad_registrar_instance;
+
+}  // namespace mfs
