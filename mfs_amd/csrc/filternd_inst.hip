@@ -11,7 +11,7 @@ NdEntry g_nd_table[8];
 
 template <int N, int TK>
 hipError_t launch_nd(const FilterNdArgs& a, int grid, hipStream_t s) {
-    constexpr int lds = NdTile<N>::kDoubles * 8;
+    constexpr int lds = NdTile<N, TK>::kDoubles * 8;
     if (hipError_t e = ensure_dynamic_lds<&filternd_kernel<N, TK>>(); e != hipSuccess) return e;
     hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
@@ -19,7 +19,8 @@ hipError_t launch_nd(const FilterNdArgs& a, int grid, hipStream_t s) {
 
 template <int N>
 void reg_nd() {
-    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, NdTile<N>::S, NdTile<N>::Z, NdTile<N>::kDoubles * 8};
+    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, NdTile<N, 0>::S, NdTile<N, 0>::Z,
+                            (NdTile<N, 0>::kDoubles > NdTile<N, 1>::kDoubles ? NdTile<N, 0>::kDoubles : NdTile<N, 1>::kDoubles) * 8};
     if constexpr (N < 7) reg_nd<N + 1>();
 }
 

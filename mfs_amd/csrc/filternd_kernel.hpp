@@ -92,7 +92,9 @@ __device__ __forceinline__ constexpr double ffact(int n, int k) {
     return r;
 }
 
-template <int N>
+// TK selects what the tile must hold: the node tables (weights, the 16-row reduction table) exist for Normal-closure
+// predictions only, the operator-term tables for operator predictions only.
+template <int N, int TK>
 struct NdTile {
     static constexpr int S = N * (N + 1) / 2;        // Gram size
     static constexpr int Z = N * (2 * N + 1);        // number of moments, |n| <= 2N - 1
@@ -106,12 +108,13 @@ struct NdTile {
     static constexpr int oK = oA + NP * LD;          // [2][NP][LD]
     static constexpr int oV = oK + 2 * NP * LD;      // [2][NP][LD]
     static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
-    static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] node weights
-    static constexpr int oLam = oW + ((R + 1) & ~1); // [2][NP]
+    static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] node weights (Normal closures)
+    static constexpr int oLam = oW + ((TK == 1) ? ((R + 1) & ~1) : 0); // [2][NP]
     static constexpr int ZB = (Z + 15) / 16;         // batches of 16 moments in the transposing reduction
     static constexpr int RW = 16 * ZB + 6;           // reduction row: moments (padded), flag, 5 scalar sums
     static constexpr int oRed = oLam + 2 * NP;       // [4 waves x 4 DPP rows][RW]
-    static constexpr int oCoef = oRed + 16 * RW;     // [kNdRows][D][D]
+    static constexpr int nRed = (TK == 1) ? 16 * RW : 16 * ZB + 16;   // operator path: Jacobi test scratch + the flag slot at [16 ZB]
+    static constexpr int oCoef = oRed + nRed;        // [kNdRows][D][D]
     static constexpr int oMisc = oCoef + kNdRows * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
     // Tournament index tables, built once per launch: which rows / columns a work item touches in round r depends on
     // (r, item) only, and recomputing it cost ~50 integer instructions per thread per round next to ~30 flops.
@@ -125,8 +128,8 @@ struct NdTile {
     static constexpr int oPK = oIdxK + nIdxK;                // [2][NPW][NP]
     static constexpr int oM = oPK + 2 * NPW * NP;            // [NPW][MLD]
     static constexpr int oM2 = oM + NPW * MLD;               // [NPW][MLD]
-    static constexpr int oQs = oM2 + NPW * MLD;              // [kNdRows][kNdMaxD * kNdMaxD]
-    static constexpr int oBin = oQs + kNdRows * kNdMaxD * kNdMaxD;  // [NPW][NPW] binomial coefficients
+    static constexpr int oQs = oM2 + NPW * MLD;              // [kNdRows][kNdMaxD * kNdMaxD] (operator path)
+    static constexpr int oBin = oQs + ((TK == 0) ? kNdRows * kNdMaxD * kNdMaxD : 0);  // [NPW][NPW] binomial coefficients
     static constexpr int oBx = oBin + NPW * NPW;             // [kNdMaxD][kNdMaxD] raw-monomial sums, then 8 scalars
     static constexpr int oLik = oBx + kNdMaxD * kNdMaxD + 8; // [2][4] likelihood factor parameters
     static constexpr int oPw = oLik + 8;                     // [2][NPW] powers of the centre shift
@@ -138,7 +141,15 @@ struct NdTile {
     static constexpr int nChV = (2 * NP > NCH) ? 2 * NP : NCH;   // two vectors of NP, or the NCH samples
     static constexpr int oChW = oChC + NCH * NCH;            // [2][NCH + nChV + 8]
     static constexpr int nChW = NCH + nChV + 8;
-    static constexpr int kDoubles = oChW + 2 * nChW;
+    // operator terms (kappa, alpha, beta) inside the extents of their blocks, packed once per launch, and n!/(n-k)!
+    static constexpr int kMaxTermWords = kNdTerms * kNdMaxD * kNdMaxD;     // 504 u32
+    static constexpr int oTerms = oChW + 2 * nChW;           // [1 + kMaxTermWords] u32 (count first)
+    static constexpr int oFf = oTerms + ((TK == 0) ? (kMaxTermWords + 2) / 2 : 0);   // [P][5]
+    static constexpr int kDoubles = oFf + ((TK == 0) ? P * 5 : 0);
+    // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
+    // moment-array tiles (free while a Jacobi runs)
+    static constexpr int oJs = (TK == 1) ? oW : oM;
+    static_assert(S * S <= 2 * NPW * MLD, "Jacobi scratch must fit in the moment-array tiles");
 };
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -219,9 +230,9 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
 
 // Front end of a rule: gather, Cholesky (or LDL^T completion), both triangular solves, symmetrisation.  Leaves the
 // symmetric K_0, K_1 in their LDS tiles; returns the block-uniform poison flag (a pivot that is not > 0).
-template <int N>
+template <int N, int TK>
 __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
     const int tid = threadIdx.x, nthr = blockDim.x;
     double* mom = Sm + L::oMom;
@@ -379,9 +390,9 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
 // Cyclic Jacobi with eigenvectors (quadratures.py:163) on the matrices m in [mbeg, mend) -- both K_k for a Normal-closure
 // prediction, only the components a likelihood factor reads for an update.  warm_mask: bit m set = V_m holds the
 // eigenvectors of an earlier rule of this filter.  On return the diagonal of K_m holds the eigenvalues, V_m the vectors.
-template <int N>
+template <int N, int TK>
 __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int mend, const int warm_mask) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
     const int tid = threadIdx.x, nthr = blockDim.x;
     double* A = Sm + L::oA;
@@ -403,7 +414,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
     //    Cholesky factor is free by now and serves as the temporary.
     if (warm_mask & (((1 << nm) - 1) << mbeg)) {
         // all warm matrices of the range in the same two stages (the weight tile, free until the end of the rule, is the second scratch)
-        double* A1 = Sm + L::oW;   // [S][S]
+        double* A1 = Sm + L::oJs;   // [S][S]
         for (int e = tid; e < nm * S * S; e += nthr) {   // A_m = K_m V_m
             const int m = mbeg + e / (S * S), f = e % (S * S), i = f / S, j = f - i * S;
             if (!((warm_mask >> m) & 1)) continue;
@@ -493,7 +504,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
                 if (i != j) Kk[i * LD + j] = Kk[i * LD + j] / (Kk[j * (LD + 1)] - Kk[i * (LD + 1)]);
             }
             __syncthreads();
-            double* T1 = Sm + L::oW;
+            double* T1 = Sm + L::oJs;
             for (int e = tid; e < nm * S * S; e += nthr) {      // T_m = V_m X_m
                 const int m = mbeg + e / (S * S), f = e % (S * S), k = f / S, j = f - k * S;
                 const double* Kk = K + m * NP * LD;
@@ -649,9 +660,9 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
 }
 
 // Eigenvalues and tensor-product weights of the s^2-node rule (quadratures.py:165-170); Normal-closure predictions only.
-template <int N>
+template <int N, int TK>
 __device__ void weights_nd(double* __restrict__ Sm) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const double* K = Sm + L::oK;
@@ -695,9 +706,9 @@ __device__ __forceinline__ double lane_matvec(const double (&kr)[S], const doubl
 // Krylov vectors PK[w][p] = K_w^p PK[w][0], p < npow, for the matrices in wmask at once: wave w owns K_w, lane i row i of
 // it in registers; a step is S lane reads of the previous vector and S multiply-adds (lane_matvec).  No block barrier inside (one
 // wave per chain); the caller synchronises before and after.
-template <int N>
+template <int N, int TK>
 __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW;
     const int tid = threadIdx.x;
     if (tid < 128 && ((wmask >> (tid >> 6)) & 1)) {
@@ -718,10 +729,10 @@ __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wma
 // M[p][q] = sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow with p + q <= maxdeg (the only entries any later stage
 // reads; the rest are zeroed): the moments sum_ij W_ij xi0_i^p xi1_j^q of the rule about its own centre
 // (xi = x - mean = scale * lambda).
-template <int N>
+template <int N, int TK>
 __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const int maxdeg, const double sc0,
                                     const double sc1) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD;
     const double* p0 = Sm + L::oPK;
     const double* p1 = Sm + L::oPK + NPW * NP;
@@ -751,10 +762,10 @@ __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, con
 // M[a][b] <- fac * sum_{j0 <= a, j1 <= b} C(a, j0) (-d0)^(a-j0) C(b, j1) (-d1)^(b-j1) M[j0][j1] for a + b <= maxdeg: the
 // same sums about the shifted centre (xi - d).  Two separable passes through M2; the powers of -d come from a small LDS
 // table so that the inner loops are plain multiply-adds.
-template <int N>
+template <int N, int TK>
 __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const int maxdeg, const double d0,
                                  const double d1, const double fac) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int NPW = L::NPW, MLD = L::MLD;
     double* M = Sm + L::oM;
     double* M2 = Sm + L::oM2;
@@ -805,11 +816,11 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
 //   h          = sum_i c_i T_i(Khat) e_0,   Khat = (K - mid) / half,  T_{i+1} = 2 Khat T_i - T_{i-1}
 // followed in the same wave by the powers PK[k][p] = K^p h, p < npow.  Wave k works on matrix k (lane i = row i); waves
 // whose component no factor reads run the plain Krylov recurrence from e_0.  No block barrier inside.
-template <int N>
+template <int N, int TK>
 __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, const int npow, const int lik_mask,
                                const double* __restrict__ ysrow, const double mean0, const double mean1,
                                const double scale0, const double scale1) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW, NCH = L::NCH;
     const int tid = threadIdx.x;
     if (tid >= 128) return;
@@ -914,7 +925,7 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
 // TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
 template <int N, int TK>
 __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) {
-    using L = NdTile<N>;
+    using L = NdTile<N, TK>;
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
     constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = kNdMaxD * kNdMaxD;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
@@ -952,6 +963,21 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         if (e < NCH) Sm[L::oChX + e] = cospi(((double)e + 0.5) / NCH);
         else { const int j = (e - NCH) / NCH, i = (e - NCH) % NCH; Sm[L::oChC + j * NCH + i] = cospi((double)i * ((double)j + 0.5) / NCH); }   // [sample j][coefficient i]
     }
+    {   // term list: word = k0 | k1 << 3 | al << 6 | be << 9 | ea << 12 | eb << 15 | (k * 36 + al * 6 + be) << 18
+        unsigned* tw = reinterpret_cast<unsigned*>(Sm + L::oTerms);
+        if (tid == 0) {
+            unsigned n = 0;
+            for (int k = 0; k < a.n_terms_used && k < kNdTerms; ++k) {
+                const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
+                for (int al = 0; al < ea; ++al)
+                    for (int be = 0; be < eb; ++be)
+                        tw[1 + n++] = (unsigned)kKap0[k] | ((unsigned)kKap1[k] << 3) | ((unsigned)al << 6) | ((unsigned)be << 9) |
+                                      ((unsigned)ea << 12) | ((unsigned)eb << 15) | ((unsigned)(k * DD6 + al * kNdMaxD + be) << 18);
+            }
+            tw[0] = n;
+        }
+        for (int e = tid; e < P * 5; e += 256) Sm[L::oFf + e] = ffact(e / 5, e % 5) * ((e % 5 <= e / 5) ? 1.0 : 0.0);
+    }
     if (tid < 8) {
         const double* src = a.lik + (a.lik_batched ? (size_t)b * a.n_factors * 4 : 0);
         Sm[L::oLik + tid] = (tid < a.n_factors * 4) ? src[tid] : 0.0;
@@ -987,7 +1013,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             // prediction (filtering.py:262-266 / :330-331 / :183-190)
             // =========================================================================================================
             {
-                const bool poisoned = front_nd<N>(Sm, a.inds, a.stable);
+                const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
                 bad = bad || poisoned;
                 double c0 = 0.0, c1 = 0.0, ns0 = 1.0, ns1 = 1.0;
                 if constexpr (TK == 0) {
@@ -996,11 +1022,11 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     const int npow = P + a.D - 1;
                     if (tid < 2 * NP) Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
                     __syncthreads();
-                    krylov_nd<N>(Sm, npow, 3);
+                    krylov_nd<N, TK>(Sm, npow, 3);
                     __syncthreads();
                     ND_STAMP(10);
                     const int maxdeg = P - 1 + 2 * (a.D - 1);     // highest total degree a re-centred block reaches from a moment
-                    bilinear_moments_nd<N>(Sm, npow, maxdeg, scale0, scale1);
+                    bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1);
                     __syncthreads();
                     ND_STAMP(11);
                     // ---- raw-monomial sums Bx[i][j] = sum W x0^i x1^j, x = xi + mean (the conditional means and
@@ -1040,57 +1066,62 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     if (!raw) { c0 = mean0 + M[1 * MLD + 0] + bx[DD6 + 0]; c1 = mean1 + M[0 * MLD + 1] + bx[DD6 + 1]; }
                     if (scaled) { ns0 = sqrt(bx[DD6 + 2]); ns1 = sqrt(bx[DD6 + 3]); }
                     ND_STAMP(12);
-                    // ---- coefficient blocks re-centred at the new mean: Q_kappa(c + eta) in powers of eta
-                    for (int e = tid; e < kNdRows * DD6; e += 256) {
-                        const int row = e / DD6, f = e - row * DD6, al = f / kNdMaxD, be = f - al * kNdMaxD;
-                        const int ea = a.ext[row] & 0xff, eb = a.ext[row] >> 8;
-                        double acc = 0.0;
-                        if (row < a.n_terms_used && al < ea && be < eb) {
-                            const double* bin = Sm + L::oBin;
-                            const double* blk = coef + row * DD;
-                            double pi = 1.0;
+                    // ---- coefficient blocks re-centred at the new mean: Q_kappa(c + eta) in powers of eta, one packed term
+                    //      (kappa, alpha, beta) per thread
+                    {
+                        const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
+                        const int nt = (int)tw[0];
+                        const double* bin = Sm + L::oBin;
+                        for (int e = tid; e < nt; e += 256) {
+                            const unsigned w = tw[1 + e];
+                            const int al = (w >> 6) & 7, be = (w >> 9) & 7, ea = (w >> 12) & 7, eb = (w >> 15) & 7, qi = w >> 18;
+                            const double* blk = coef + (qi / DD6) * DD;
+                            double acc = 0.0, pi = 1.0;
                             for (int i = al; i < ea; ++i) {
                                 double pj = 1.0, rsum = 0.0;
                                 for (int j = be; j < eb; ++j) { rsum = fma(bin[j * NPW + be] * pj, blk[i * a.D + j], rsum); pj *= c1; }
                                 acc = fma(bin[i * NPW + al] * pi, rsum, acc);
                                 pi *= c0;
                             }
+                            qs[qi] = acc;
                         }
-                        qs[e] = acc;
                     }
                     // ---- the moment array about the new mean
                     ND_STAMP(13);
-                    shift_moments_nd<N>(Sm, npow, maxdeg, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
+                    shift_moments_nd<N, TK>(Sm, npow, maxdeg, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
                     ND_STAMP(14);
                     // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)],
                     //      the kappa terms of a moment spread over four threads (partial sums through the free M2 tile)
                     {
                         double* part = Sm + L::oM2;      // [4][Z]
                         static_assert(4 * Z <= NPW * MLD, "partial sums must fit in the M2 tile");
+                        const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
+                        const int nt = (int)tw[0];
+                        const double* ff = Sm + L::oFf;
                         for (int e = tid; e < 4 * Z; e += 256) {
                             const int grp = e / Z, zi = e - grp * Z;
                             int sd = 0;
                             while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
                             const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                            double v = (grp == 0) ? M[n0 * MLD + n1] : 0.0;
-                            for (int k = grp; k < a.n_terms_used; k += 4) {
-                                const int k0 = kKap0[k], k1 = kKap1[k];
-                                const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
-                                if (k0 > n0 || k1 > n1 || ea == 0) continue;
-                                const double* q = qs + k * DD6;
-                                const double* Mr = M + (n0 - k0) * MLD + (n1 - k1);
-                                double acc0 = 0.0, acc1 = 0.0;
-                                for (int al = 0; al < ea; ++al) {
-                                    int be = 0;
-                                    for (; be + 1 < eb; be += 2) {
-                                        acc0 = fma(q[al * kNdMaxD + be], Mr[al * MLD + be], acc0);
-                                        acc1 = fma(q[al * kNdMaxD + be + 1], Mr[al * MLD + be + 1], acc1);
-                                    }
-                                    if (be < eb) acc0 = fma(q[al * kNdMaxD + be], Mr[al * MLD + be], acc0);
+                            double v0 = (grp == 0) ? M[n0 * MLD + n1] : 0.0, v1 = 0.0;
+                            const double* f0 = ff + n0 * 5;
+                            const double* f1 = ff + n1 * 5;
+                            // (a term with kappa > n has a zero falling factorial: its M index is clamped, not branched on)
+                            for (int t = grp; t < nt; t += 8) {
+                                const unsigned wa = tw[1 + t];
+                                const unsigned wb = (t + 4 < nt) ? tw[1 + t + 4] : 0u;
+                                {
+                                    const int k0 = wa & 7, k1 = (wa >> 3) & 7, al = (wa >> 6) & 7, be = (wa >> 9) & 7;
+                                    const int r0 = max(n0 - k0, 0) + al, r1 = max(n1 - k1, 0) + be;
+                                    v0 = fma(f0[k0] * f1[k1] * qs[wa >> 18], M[r0 * MLD + r1], v0);
                                 }
-                                v = fma(ffact(n0, k0) * ffact(n1, k1), acc0 + acc1, v);
+                                if (t + 4 < nt) {
+                                    const int k0 = wb & 7, k1 = (wb >> 3) & 7, al = (wb >> 6) & 7, be = (wb >> 9) & 7;
+                                    const int r0 = max(n0 - k0, 0) + al, r1 = max(n1 - k1, 0) + be;
+                                    v1 = fma(f0[k0] * f1[k1] * qs[wb >> 18], M[r0 * MLD + r1], v1);
+                                }
                             }
-                            part[e] = v;
+                            part[e] = v0 + v1;
                         }
                         __syncthreads();
                         for (int zi = tid; zi < Z; zi += 256) {
@@ -1113,8 +1144,8 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 } else {
                     // ---- Normal closure: the s^2 nodes explicitly.  Both K_k diagonalised, weights, then per node the
                     //      Stein recursion (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), moments.py:110-154)
-                    jacobi_nd<N>(Sm, 0, 2, poisoned ? 0 : warm_mask);
-                    weights_nd<N>(Sm);
+                    jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
+                    weights_nd<N, TK>(Sm);
                     warm_mask = poisoned ? 0 : 3;
                     ND_STAMP_BEGIN;
                     const double* lam = Sm + L::oLam;
@@ -1230,17 +1261,17 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             // update (filtering.py:268-275 / :333-339 / :192-202): bilinear form with h_k = lik_k(X_k) e_0
             // =========================================================================================================
             {
-                const bool poisoned = front_nd<N>(Sm, a.inds, a.stable);
+                const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
                 bad = bad || poisoned;
                 // h_k = lik_k(X_k) e_0 and the powers K_k^p h_k: Chebyshev evaluation (no eigen-decomposition), checked;
                 // cyclic Jacobi + spectral evaluation only if the coefficients of some factor have not converged
                 ND_STAMP_BEGIN;
                 if (tid == 0) Sm[L::oMisc + 6] = 0.0;
                 __syncthreads();
-                cheb_krylov_nd<N>(Sm, a, P, MFS_ND_FORCE_JACOBI ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
+                cheb_krylov_nd<N, TK>(Sm, a, P, MFS_ND_FORCE_JACOBI ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
                 __syncthreads();
                 if (MFS_ND_FORCE_JACOBI || Sm[L::oMisc + 6] != 0.0) {
-                    jacobi_nd<N>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
+                    jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
                     warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
                     __syncthreads();
                     // ---- g_k[i] = lik_k(x_k,i) V_k[0][i], the spectral coefficients of h_k (or h_k = e_0 where no factor reads
@@ -1285,11 +1316,11 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                         if constexpr (S & 1) a0 = fma(Vr[S - 1], gl[S - 1], a0);
                         Sm[L::oPK + (k * NPW + p) * NP + r] = a0 + a1;
                     }
-                    krylov_nd<N>(Sm, P, 3 & ~lik_mask);
+                    krylov_nd<N, TK>(Sm, P, 3 & ~lik_mask);
                     __syncthreads();
                 }
                 ND_STAMP(15);
-                bilinear_moments_nd<N>(Sm, P, P - 1, scale0, scale1);
+                bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1);
                 __syncthreads();
                 const double py = M[0];
                 const double ipy = 1.0 / py;
@@ -1297,7 +1328,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
                 nell -= fast_log(py);
                 __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
-                shift_moments_nd<N>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
+                shift_moments_nd<N, TK>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
                 for (int zi = tid; zi < Z; zi += 256) {
