@@ -756,6 +756,7 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
         a.fac_kind[f] = model->fac_kind[f]; a.fac_comp[f] = model->fac_component[f]; a.fac_ycol[f] = model->fac_ycol[f];
     }
     a.coef_batched = model->coef_batched; a.lik_batched = model->lik_batched;
+    if (const char* e = getenv("MFS_ND_UPDATE")) a.force_eigen = (strcmp(e, "eigen") == 0);   // A/B switch, like MFS_SOLVER
     // true extents of each coefficient block (trailing zero rows / columns cut); the union over replicates when batched
     const size_t ntab = model->coef_batched ? (size_t)B : 1;
     for (int k = 0; k < MFS_ND_ROWS; ++k) {

@@ -49,6 +49,7 @@ struct FilterNdArgs {
     int n_factors, ny;        // likelihood = prod_f lik(kind_f, params_f, y[ycol_f], x[comp_f]);  ys is [B][T][ny]
     int fac_kind[2], fac_comp[2], fac_ycol[2];
     int coef_batched, lik_batched;
+    int force_eigen;          // 1: every update diagonalises K_k (the checked fallback of the Chebyshev evaluation, as the only route)
     int ext[16];              // per-block true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
     const double* coef;       // [kNdRows][D][D] (or [B][...]): rows 0..13 Q_kappa in the fixed kappa order below (zeros
                               // where the model has no term), rows 14, 15 the conditional variances of X'_0, X'_1 (scaled mode)
@@ -1268,9 +1269,9 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 ND_STAMP_BEGIN;
                 if (tid == 0) Sm[L::oMisc + 6] = 0.0;
                 __syncthreads();
-                cheb_krylov_nd<N, TK>(Sm, a, P, MFS_ND_FORCE_JACOBI ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
+                cheb_krylov_nd<N, TK>(Sm, a, P, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
                 __syncthreads();
-                if (MFS_ND_FORCE_JACOBI || Sm[L::oMisc + 6] != 0.0) {
+                if (MFS_ND_FORCE_JACOBI || a.force_eigen || Sm[L::oMisc + 6] != 0.0) {
                     jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
                     warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
                     __syncthreads();

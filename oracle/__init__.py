@@ -18,13 +18,24 @@ Pinning status ("how do we know the restatement is the reference's algorithm?"):
     two 1-D filters (:244-329), quadrature exactness (tests/test_one_dim_quadrature.py:48-113,
     tests/test_multi_dim_quadrature.py), TME vs exact LTI discretisation
     (tests/test_one_dim_moments.py:90-118), `ldl_chol` == Cholesky (tests/test_utils.py:198-209),
+    the N-D transition factories against exact LTI moments (tests/test_multi_dim_moments.py:149-246),
+    the N-D rule on quadratic / mgf integrands and under basis reordering
+    (tests/test_multi_dim_quadrature.py:169-216, 226-265) -- tests/test_oracle_pins.py --
     and by golden multi-index tables generated from the one reference module that does import
     (`mfs/multi_dims/multi_indices.py`, pure NumPy; `tests/golden/make_multi_indices_golden.py`).
+  * Oracle outputs for BASELINE configs 1-5 are frozen under `tests/golden/filter_cfg*.npz`
+    (`tests/golden/make_filter_golden.py`); the GPU parity tests read them.
   * Third-party arithmetic: the transition moments come from PyPI `tme` (>=0.1.5, unpinned; not
     vendored in the reference).  `oracle/tme_sympy.py` restates its published algorithm
     (Zhao et al., "Taylor moment expansion for continuous-discrete Gaussian filtering", IEEE TAC 2021)
     and is anchored on the reference's call sites and its LTI tests.
   * For the Benes (tanh-drift) model the reference holds no pinned value at all: **parity unpinned**
-    at that model.  Anchor used instead: the exact Benes transition law, whose mean/variance the TME
-    expansion reproduces exactly (tests/test_oracle_one_dim.py::test_benes_tme_matches_exact_law).
+    by the reference at that model.  Anchors used instead: the exact Benes transition law, whose
+    mean/variance the TME expansion reproduces exactly
+    (tests/test_oracle_one_dim.py::test_benes_tme_matches_exact_law), and `oracle/exact_mp.py` -- the same
+    filter in 80-digit arithmetic with exact rational TME tables (mpmath), the arbiter at N = 15 where two
+    correct fp64 implementations (this package on LAPACK, `oracle/c`) disagree about when a replicate
+    NaN-poisons (`tests/golden/filter_cfg2_exact*.npz`, `tests/test_gpu_envelope.py`).
+  * `oracle/parity.py`: the error measures shared by the tests and `bench.py` (per-order moment floors,
+    first-NaN agreement).
 """

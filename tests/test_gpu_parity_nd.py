@@ -52,7 +52,7 @@ def test_prey_predator_central_and_raw(N, T, tme_order):
         rc = omd.moment_filter_nd_cms((ofns[1], 'multi-index'), ofns[2], opmf, ys[b], (mi, inds), ogs.cms, ogs.mean)
         npt.assert_allclose(nell[b], rc[2], rtol=1e-6)
         npt.assert_allclose(means[b], rc[1], rtol=1e-6)
-        _assert_moments(cmss[b], rc[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
+        _assert_moments(cmss[b], rc[0], mi, rtol=1e-6)
         if N <= 4:
             rr = omd.moment_filter_nd_rms((ofns[0], 'multi-index'), opmf, ys[b], (mi, inds), ogs.rms)
             npt.assert_allclose(nell_r[b], rr[1], rtol=1e-6)
@@ -161,3 +161,33 @@ def test_prey_predator_scaled_mode(N, T, family):
     _assert_moments(scmss[0], rs[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
     with pytest.raises(sym.NotDeviceDescribable):   # the mean-only closure is not the mean-and-variance closure
         filtering.moment_filter_nd_scms((fns[2], sig), fns[3], pmf, ys, (mi, inds), scms0, gs.mean, scale0)
+
+
+@pytest.mark.parametrize('N,T,family', [(4, 40, 'tme_2'), (6, 30, 'tme_2'), (4, 30, 'tme_normal_2')])
+def test_update_by_eigen_decomposition_matches_chebyshev_route(N, T, family, monkeypatch):
+    """The update half evaluates lik_k(X_k) e_0 by a checked Chebyshev interpolant and falls back to diagonalising K_k
+    (quadratures.py:163 as the reference does it) when the coefficient tail has not converged.  MFS_ND_UPDATE=eigen
+    makes the fallback the only route: both must give the reference's numbers."""
+    mi, inds, dt, gs, fns, pmf, ogs, ofns, opmf = _setup(N, 2)
+    if family == 'tme_normal_2':
+        _, _, _, _, drift, disp, _, _, _ = ss_models.prey_predator(mi)
+        nf = moments.sde_cond_moments_tme_normal(drift, disp, dt, 2, mi)
+        trans, mean_fn = (nf[1], 'index'), nf[3]
+    else:
+        trans, mean_fn = (fns[1], 'multi-index'), fns[3]
+    B = 2
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=40 + N)
+    cheb = filtering.moment_filter_nd_cms(trans, mean_fn, pmf, ys, (mi, inds), gs.cms, gs.mean)
+    monkeypatch.setenv('MFS_ND_UPDATE', 'eigen')
+    eig = filtering.moment_filter_nd_cms(trans, mean_fn, pmf, ys, (mi, inds), gs.cms, gs.mean)
+    monkeypatch.delenv('MFS_ND_UPDATE')
+    assert np.all(np.isfinite(cheb[2])) and np.all(np.isfinite(eig[2]))
+    npt.assert_allclose(eig[2], cheb[2], rtol=1e-9)
+    npt.assert_allclose(eig[1], cheb[1], rtol=1e-9)
+    for b in range(B):
+        _assert_moments(eig[0][b], cheb[0][b], mi, rtol=1e-6)
+    if family == 'tme_2':
+        rc = omd.moment_filter_nd_cms((ofns[1], 'multi-index'), ofns[2], opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
+        npt.assert_allclose(eig[2][0], rc[2], rtol=1e-6)
+        npt.assert_allclose(eig[1][0], rc[1], rtol=1e-6)
+        _assert_moments(eig[0][0], rc[0], mi, rtol=1e-6)

@@ -23,7 +23,8 @@ int main(int argc, char** argv) {
     a.fac_kind[0] = 0; a.fac_comp[0] = 0; a.fac_ycol[0] = 0; for (int k = 0; k < kNdRows; ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
     a.out_mom = nullptr; a.out_mean = dmeans; a.out_nell = dnell; a.out_first_nan = nullptr;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((filternd_kernel<N, 0>), dim3(B), dim3(256), NdTile<N, 0>::kDoubles * 8, 0, a);
+    constexpr int lds = NdTile<N, 0>::kDoubles * 8;
+    hipLaunchKernelGGL((filternd_kernel<N, 0>), dim3(B), dim3(256), lds, 0, a);
     hipDeviceSynchronize();
     unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
     const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
