@@ -145,7 +145,10 @@ struct NdTile {
     // operator terms (kappa, alpha, beta) inside the extents of their blocks, packed once per launch, and n!/(n-k)!
     static constexpr int kMaxTermWords = kNdTerms * kNdMaxD * kNdMaxD;     // 504 u32
     static constexpr int oTerms = oChW + 2 * nChW;           // [1 + kMaxTermWords] u32 (count first)
-    static constexpr int oFf = oTerms + ((TK == 0) ? (kMaxTermWords + 2) / 2 : 0);   // [P][5]
+    static constexpr int kTermChunk = 8;                     // terms a thread has in flight at once in the contraction
+    static constexpr int kTermGroups = (4 * Z <= 256) ? 4 : (3 * Z <= 256) ? 3 : (2 * Z <= 256) ? 2 : 1;   // threads per moment
+    static constexpr int kTermPad = kTermGroups * kTermChunk;   // the list is padded to a multiple of this with zero terms
+    static constexpr int oFf = oTerms + ((TK == 0) ? (kMaxTermWords + kTermPad + 2) / 2 : 0);   // [P][5]
     static constexpr int kDoubles = oFf + ((TK == 0) ? P * 5 : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
     // moment-array tiles (free while a Jacobi runs)
@@ -165,6 +168,23 @@ __device__ __forceinline__ double wave_sum64(double v) {
         const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * r);
         const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
         tot += __hiloint2double(hi, lo);
+    }
+    return tot;
+}
+
+// wave-wide maximum in every lane, same DPP ladder as wave_sum64 (a shuffle-xor butterfly of doubles is two ds_bpermute
+// round trips per step, ~1.5 k cycles for the two extrema of a Gershgorin interval)
+__device__ __forceinline__ double wave_max64(double v) {
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x140>(v));
+    double tot = -1.79e308;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), 16 * r);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 16 * r);
+        tot = fmax(tot, __hiloint2double(hi, lo));
     }
     return tot;
 }
@@ -704,6 +724,24 @@ __device__ __forceinline__ double lane_matvec(const double (&kr)[S], const doubl
     return (a0 + a1) + a2;
 }
 
+// The same product with the vector in LDS (every lane reads the whole vector: broadcast reads, conflict-free, all issued
+// before the first multiply-add).  The lane-read form above compiles to readlane pairs through ONE scalar register pair,
+// i.e. readlane, readlane, hazard nop, multiply-add strictly in turn (~30 cycles per entry); here the S multiply-adds
+// issue back to back once the reads land.  Same summation order: the two forms are bit-identical.
+template <int S>
+__device__ __forceinline__ double lds_matvec(const double (&kr)[S], const double* __restrict__ u) {
+    double uv[S];
+    static_for<0, S>([&](auto Jc) { uv[Jc] = u[Jc]; });
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    static_for<0, S>([&](auto Jc) {
+        constexpr int j = Jc;
+        if constexpr (j % 3 == 0) a0 = fma(kr[j], uv[j], a0);
+        else if constexpr (j % 3 == 1) a1 = fma(kr[j], uv[j], a1);
+        else a2 = fma(kr[j], uv[j], a2);
+    });
+    return (a0 + a1) + a2;
+}
+
 // Krylov vectors PK[w][p] = K_w^p PK[w][0], p < npow, for the matrices in wmask at once: wave w owns K_w, lane i row i of
 // it in registers; a step is S lane reads of the previous vector and S multiply-adds (lane_matvec).  No block barrier inside (one
 // wave per chain); the caller synchronises before and after.
@@ -719,10 +757,10 @@ __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wma
         double kr[S];
         static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
         wave_sync();
-        double u = pk[li];                        // the start vector, one entry per lane
         for (int p = 1; p < npow; ++p) {
-            u = lane_matvec<S>(kr, u);
+            const double u = lds_matvec<S>(kr, pk + (p - 1) * NP);
             if (lane < S) pk[p * NP + lane] = u;
+            wave_sync();
         }
     }
 }
@@ -763,7 +801,7 @@ __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, con
 // M[a][b] <- fac * sum_{j0 <= a, j1 <= b} C(a, j0) (-d0)^(a-j0) C(b, j1) (-d1)^(b-j1) M[j0][j1] for a + b <= maxdeg: the
 // same sums about the shifted centre (xi - d).  Two separable passes through M2; the powers of -d come from a small LDS
 // table so that the inner loops are plain multiply-adds.
-template <int N, int TK>
+template <int N, int TK, int NJ>
 __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const int maxdeg, const double d0,
                                  const double d1, const double fac) {
     using L = NdTile<N, TK>;
@@ -778,29 +816,41 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
         for (int k = 0; k < NPW; ++k) { pw[threadIdx.x * NPW + k] = v; v *= d; }
     }
     __syncthreads();
+    // Fixed trip count NJ >= nout with every LDS read of an entry issued before any arithmetic (terms j > a are masked by
+    // a select on the loaded value, not by a branch): a loop to the true bound a was one dependent LDS round trip per term.
     for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q], q <= maxdeg - a
         const int a = e / nout, q = e - a * nout;
         if (a + q > maxdeg) continue;
+        double c[NJ], v[NJ];
+        static_for<0, NJ>([&](auto Jc) {
+            constexpr int j = Jc;
+            c[j] = bin[a * NPW + j] * pw[max(a - j, 0)];
+            v[j] = M[j * MLD + q];
+        });
         double acc0 = 0.0, acc1 = 0.0;
-        int j = 0;
-        for (; j + 1 <= a; j += 2) {
-            acc0 = fma(bin[a * NPW + j] * pw[a - j], M[j * MLD + q], acc0);
-            acc1 = fma(bin[a * NPW + j + 1] * pw[a - j - 1], M[(j + 1) * MLD + q], acc1);
-        }
-        if (j <= a) acc0 = fma(bin[a * NPW + j] * pw[a - j], M[j * MLD + q], acc0);
+        static_for<0, NJ>([&](auto Jc) {
+            constexpr int j = Jc;
+            const double vj = (j <= a) ? v[j] : 0.0;
+            if constexpr (j % 2 == 0) acc0 = fma(c[j], vj, acc0); else acc1 = fma(c[j], vj, acc1);
+        });
         M2[a * MLD + q] = acc0 + acc1;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
         const int a = e / nout, b = e - a * nout;
         if (a + b > maxdeg) continue;
+        double c[NJ], v[NJ];
+        static_for<0, NJ>([&](auto Jc) {
+            constexpr int j = Jc;
+            c[j] = bin[b * NPW + j] * pw[NPW + max(b - j, 0)];
+            v[j] = M2[a * MLD + j];
+        });
         double acc0 = 0.0, acc1 = 0.0;
-        int j = 0;
-        for (; j + 1 <= b; j += 2) {
-            acc0 = fma(bin[b * NPW + j] * pw[NPW + b - j], M2[a * MLD + j], acc0);
-            acc1 = fma(bin[b * NPW + j + 1] * pw[NPW + b - j - 1], M2[a * MLD + j + 1], acc1);
-        }
-        if (j <= b) acc0 = fma(bin[b * NPW + j] * pw[NPW + b - j], M2[a * MLD + j], acc0);
+        static_for<0, NJ>([&](auto Jc) {
+            constexpr int j = Jc;
+            const double vj = (j <= b) ? v[j] : 0.0;
+            if constexpr (j % 2 == 0) acc0 = fma(c[j], vj, acc0); else acc1 = fma(c[j], vj, acc1);
+        });
         M[a * MLD + b] = (acc0 + acc1) * fac;
     }
     __syncthreads();
@@ -845,9 +895,7 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
             static_for<0, S>([&](auto Jc) { if (Jc == li) dg = kr[Jc]; });
             rad -= fabs(dg);
             double lo = (lane < S) ? dg - rad : 1.79e308, hi = (lane < S) ? dg + rad : -1.79e308;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
-            dmin = lo; dmax = hi;
+            dmin = -wave_max64(-lo); dmax = wave_max64(hi);
         }
         const double mid = 0.5 * (dmin + dmax);
         double half = 0.5 * (dmax - dmin);
@@ -874,8 +922,7 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
             const double c = (c0 + c1) * ((i == 0) ? 1.0 / NCH : 2.0 / NCH);
             // tail and largest coefficient (wave reductions), effective degree
             double big = (lane < NCH) ? fabs(c) : 0.0, tail = (lane < NCH && lane >= NCH - 3) ? fabs(c) : 0.0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { big = fmax(big, __shfl_xor(big, o, 64)); tail = fmax(tail, __shfl_xor(tail, o, 64)); }
+            big = wave_max64(big); tail = wave_max64(tail);
             const bool ok = (tail <= 1e-14 * big) && finite(big);
             unsigned long long live = __ballot((lane < NCH) && (fabs(c) > 2e-15 * big));   // below: the rounding noise of the transform itself (~1e-15 of the largest)
             const int deg = ok ? (live ? 63 - __builtin_clzll(live) : 0) : -1;
@@ -895,13 +942,21 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
         double tprev = (li == 0) ? 1.0 : 0.0;     // T_0 e_0
         double tcur = kr[0];                      // T_1 e_0 = Khat e_0: column 0 = row 0 (symmetric), entry li
         double h = fma(cf[1], tcur, cf[0] * tprev);
+        wave_sync();                              // the sample buffer is free: it now carries T_i e_0, ping-pong
+        if (lane < S) vbuf[lane] = tcur;
+        wave_sync();
         for (int i = 2; i <= deg; ++i) {
-            const double tnext = fma(2.0, lane_matvec<S>(kr, tcur), -tprev);
+            const double* src = vbuf + (i & 1) * NP;
+            double* dst = vbuf + ((i & 1) ^ 1) * NP;
+            const double tnext = fma(2.0, lds_matvec<S>(kr, src), -tprev);
             h = fma(cf[i], tnext, h);
+            if (lane < S) dst[lane] = tnext;
+            wave_sync();
             tprev = tcur; tcur = tnext;
         }
         if (deg < 1) h = cf[0] * tprev;
         if (lane < S) pk[lane] = h;
+        wave_sync();
         ND_STAMP(18);
 #ifdef MFS_ND_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[20] += deg;
@@ -909,16 +964,18 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
         // ---- powers of K itself: K u = half Khat u + mid u
         double u = h;
         for (int p = 1; p < npow; ++p) {
-            u = fma(half, lane_matvec<S>(kr, u), mid * u);
+            u = fma(half, lds_matvec<S>(kr, pk + (p - 1) * NP), mid * u);
             if (lane < S) pk[p * NP + lane] = u;
+            wave_sync();
         }
         ND_STAMP(19);
     } else {
         if (lane < NP) pk[lane] = (lane == 0) ? 1.0 : 0.0;
-        double u = (lane == 0) ? 1.0 : 0.0;
+        wave_sync();
         for (int p = 1; p < npow; ++p) {
-            u = lane_matvec<S>(kr, u);
+            const double u = lds_matvec<S>(kr, pk + (p - 1) * NP);
             if (lane < S) pk[p * NP + lane] = u;
+            wave_sync();
         }
     }
 }
@@ -964,7 +1021,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         if (e < NCH) Sm[L::oChX + e] = cospi(((double)e + 0.5) / NCH);
         else { const int j = (e - NCH) / NCH, i = (e - NCH) % NCH; Sm[L::oChC + j * NCH + i] = cospi((double)i * ((double)j + 0.5) / NCH); }   // [sample j][coefficient i]
     }
-    {   // term list: word = k0 | k1 << 3 | al << 6 | be << 9 | ea << 12 | eb << 15 | (k * 36 + al * 6 + be) << 18
+    if constexpr (TK == 0) {   // term list: word = k0 | k1 << 3 | al << 6 | be << 9 | ea << 12 | eb << 15 | (k * 36 + al * 6 + be) << 18
         unsigned* tw = reinterpret_cast<unsigned*>(Sm + L::oTerms);
         if (tid == 0) {
             unsigned n = 0;
@@ -976,7 +1033,10 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                                       ((unsigned)ea << 12) | ((unsigned)eb << 15) | ((unsigned)(k * DD6 + al * kNdMaxD + be) << 18);
             }
             tw[0] = n;
+            // pad to whole chunks with terms that read the always-zero slot of the re-centred table
+            for (int q = 0; q < L::kTermPad; ++q) tw[1 + n + q] = (unsigned)(kNdTerms * DD6) << 18;
         }
+        if (tid == 0) Sm[L::oQs + kNdTerms * DD6] = 0.0;
         for (int e = tid; e < P * 5; e += 256) Sm[L::oFf + e] = ffact(e / 5, e % 5) * ((e % 5 <= e / 5) ? 1.0 : 0.0);
     }
     if (tid < 8) {
@@ -1030,37 +1090,35 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1);
                     __syncthreads();
                     ND_STAMP(11);
-                    // ---- raw-monomial sums Bx[i][j] = sum W x0^i x1^j, x = xi + mean (the conditional means and
-                    //      variances are polynomials in x): binomial un-shift of the low corner of M
-                    int bxa = 0, bxb = 0;    // extents of the blocks that read the raw-monomial sums: means and variances
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const int row = (r4 < 2) ? r4 : 12 + r4;
-                        if (r4 >= 2 && !scaled) continue;
-                        bxa = max(bxa, a.ext[row] & 0xff); bxb = max(bxb, a.ext[row] >> 8);
-                    }
-                    if (tid < DD6) {
-                        const int i = tid / kNdMaxD, j = tid - i * kNdMaxD;
+                    // ---- sums of the mean rows (and, scaled mode, the variance rows) of the table over the rule: each is a
+                    //      polynomial in x = xi + mean, so sum W Q(x) = sum_{al,be} Q'[al][be] M[al][be] with Q' the block
+                    //      re-centred at the rule's centre.  One wave per row, one (i, j, al, be) product per lane and pass, all
+                    //      LDS reads independent, then a wave sum (the two nested per-thread loops this replaces were
+                    //      5 k cycles of dependent LDS round trips per step).
+                    {
+                        const int r4 = tid >> 6, lane = tid & 63;
+                        const int row = (r4 == 0) ? 1 : (r4 == 1) ? 0 : 12 + r4;   // kappa (1,0) is row 1, (0,1) row 0; 14, 15 variances
                         double acc = 0.0;
-                        if (i < bxa && j < bxb) {
+                        if (r4 < 2 || scaled) {
+                            const int ea = a.ext[row] & 0xff, eb = a.ext[row] >> 8;
+                            const int ta = ea * (ea + 1) / 2, tb = eb * (eb + 1) / 2;
                             const double* bin = Sm + L::oBin;
-                            double pi = 1.0;
-                            for (int al = i; al >= 0; --al) {
-                                double pj = 1.0, row = 0.0;
-                                for (int be = j; be >= 0; --be) { row = fma(bin[j * NPW + be] * pj, M[al * MLD + be], row); pj *= mean1; }
-                                acc = fma(bin[i * NPW + al] * pi, row, acc);
-                                pi *= mean0;
+                            for (int e = lane; e < ta * tb; e += 64) {
+                                const int pa = e / tb, pb = e - pa * tb;
+                                int i = 0, j = 0;
+                                while ((i + 1) * (i + 2) / 2 <= pa) ++i;
+                                while ((j + 1) * (j + 2) / 2 <= pb) ++j;
+                                const int al = pa - i * (i + 1) / 2, be = pb - j * (j + 1) / 2;
+                                const double cv = coef[row * DD + i * a.D + j], b0 = bin[i * NPW + al], b1 = bin[j * NPW + be];
+                                const double mv = M[al * MLD + be];
+                                double pw = 1.0;
+                                for (int q = 0; q < i - al; ++q) pw *= mean0;
+                                for (int q = 0; q < j - be; ++q) pw *= mean1;
+                                acc = fma(cv * b0 * b1 * pw, mv, acc);
                             }
                         }
-                        bx[tid] = acc;
-                    }
-                    __syncthreads();
-                    if (tid < 4) {   // 0, 1: E[X'_k] - x_k summed; 2, 3: conditional variances (scaled mode)
-                        const int row = (tid == 0) ? 1 : (tid == 1) ? 0 : 12 + tid;   // kappa (1,0) is row 1, (0,1) row 0
-                        const int ea = a.ext[row] & 0xff, eb = a.ext[row] >> 8;
-                        double acc = 0.0;
-                        for (int i = 0; i < ea; ++i)
-                            for (int j = 0; j < eb; ++j) acc = fma(coef[row * DD + i * a.D + j], bx[i * kNdMaxD + j], acc);
-                        bx[DD6 + tid] = acc;
+                        acc = wave_sum64(acc);
+                        if (lane == 0) bx[DD6 + r4] = acc;
                     }
                     __syncthreads();
                     // E[X'_k | x] = x_k + Q_{e_k}(x): the mean of the prediction is the rule's own first moment plus the sum
@@ -1089,47 +1147,53 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     }
                     // ---- the moment array about the new mean
                     ND_STAMP(13);
-                    shift_moments_nd<N, TK>(Sm, npow, maxdeg, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
+                    shift_moments_nd<N, TK, NPW - 1>(Sm, npow, maxdeg, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
                     ND_STAMP(14);
                     // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)],
                     //      the kappa terms of a moment spread over four threads (partial sums through the free M2 tile)
                     {
-                        double* part = Sm + L::oM2;      // [4][Z]
-                        static_assert(4 * Z <= NPW * MLD, "partial sums must fit in the M2 tile");
+                        double* part = Sm + L::oM2;      // [groups][Z]
+                        constexpr int GR = L::kTermGroups, CH = L::kTermChunk;
+                        static_assert(GR * Z <= NPW * MLD, "partial sums must fit in the M2 tile");
                         const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
                         const int nt = (int)tw[0];
                         const double* ff = Sm + L::oFf;
-                        for (int e = tid; e < 4 * Z; e += 256) {
-                            const int grp = e / Z, zi = e - grp * Z;
+                        if (tid < GR * Z) {
+                            const int grp = tid / Z, zi = tid - grp * Z;
                             int sd = 0;
                             while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
                             const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
                             double v0 = (grp == 0) ? M[n0 * MLD + n1] : 0.0, v1 = 0.0;
                             const double* f0 = ff + n0 * 5;
                             const double* f1 = ff + n1 * 5;
-                            // (a term with kappa > n has a zero falling factorial: its M index is clamped, not branched on)
-                            for (int t = grp; t < nt; t += 8) {
-                                const unsigned wa = tw[1 + t];
-                                const unsigned wb = (t + 4 < nt) ? tw[1 + t + 4] : 0u;
-                                {
-                                    const int k0 = wa & 7, k1 = (wa >> 3) & 7, al = (wa >> 6) & 7, be = (wa >> 9) & 7;
+                            // A chunk of CH terms at a time, every LDS read of the chunk issued before any arithmetic: the
+                            // term words first, then the four operands of each term (the one-term-at-a-time loop was two
+                            // dependent LDS round trips per term, 18 k cycles per step).  A term with kappa > n has a zero
+                            // falling factorial: its M index is clamped, not branched on; the list is padded with zero terms.
+                            for (int t0 = grp * CH; t0 < nt; t0 += GR * CH) {
+                                unsigned w[CH];
+                                static_for<0, CH>([&](auto Jc) { w[Jc] = tw[1 + t0 + Jc]; });
+                                double fa[CH], fb[CH], q[CH], mv[CH];
+                                static_for<0, CH>([&](auto Jc) {
+                                    const unsigned wj = w[Jc];
+                                    const int k0 = wj & 7, k1 = (wj >> 3) & 7, al = (wj >> 6) & 7, be = (wj >> 9) & 7;
                                     const int r0 = max(n0 - k0, 0) + al, r1 = max(n1 - k1, 0) + be;
-                                    v0 = fma(f0[k0] * f1[k1] * qs[wa >> 18], M[r0 * MLD + r1], v0);
-                                }
-                                if (t + 4 < nt) {
-                                    const int k0 = wb & 7, k1 = (wb >> 3) & 7, al = (wb >> 6) & 7, be = (wb >> 9) & 7;
-                                    const int r0 = max(n0 - k0, 0) + al, r1 = max(n1 - k1, 0) + be;
-                                    v1 = fma(f0[k0] * f1[k1] * qs[wb >> 18], M[r0 * MLD + r1], v1);
-                                }
+                                    fa[Jc] = f0[k0]; fb[Jc] = f1[k1]; q[Jc] = qs[wj >> 18]; mv[Jc] = M[r0 * MLD + r1];
+                                });
+                                static_for<0, CH>([&](auto Jc) {
+                                    if constexpr (Jc % 2 == 0) v0 = fma(fa[Jc] * fb[Jc] * q[Jc], mv[Jc], v0);
+                                    else v1 = fma(fa[Jc] * fb[Jc] * q[Jc], mv[Jc], v1);
+                                });
                             }
-                            part[e] = v0 + v1;
+                            part[tid] = v0 + v1;
                         }
                         __syncthreads();
                         for (int zi = tid; zi < Z; zi += 256) {
                             int sd = 0;
                             while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
                             const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                            double v = (part[zi] + part[Z + zi]) + (part[2 * Z + zi] + part[3 * Z + zi]);
+                            double v = part[zi];
+                            static_for<1, L::kTermGroups>([&](auto Gc) { v += part[Gc * Z + zi]; });
                             if (scaled) {
                                 const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
                                 double f = 1.0;
@@ -1329,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
                 nell -= fast_log(py);
                 __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
-                shift_moments_nd<N, TK>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
+                shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
                 for (int zi = tid; zi < Z; zi += 256) {
