@@ -708,42 +708,44 @@ __device__ void weights_nd(double* __restrict__ Sm) {
 // ---------------------------------------------------------------------------------------------------------------------
 // bilinear-form path (identity (*) at the top of this file)
 // ---------------------------------------------------------------------------------------------------------------------
-// Row-times-vector with the vector distributed one entry per lane (lane j holds u_j): v_readlane brings u_j into scalar
-// registers, so a step of a Krylov / Chebyshev recurrence makes no LDS round trip at all.
-template <int S>
-__device__ __forceinline__ double lane_matvec(const double (&kr)[S], const double u) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    static_for<0, S>([&](auto Jc) {
-        constexpr int j = Jc;
-        const double uj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(u), j),
-                                           __builtin_amdgcn_readlane(__double2loint(u), j));
-        if constexpr (j % 3 == 0) a0 = fma(kr[j], uj, a0);
-        else if constexpr (j % 3 == 1) a1 = fma(kr[j], uj, a1);
-        else a2 = fma(kr[j], uj, a2);
-    });
-    return (a0 + a1) + a2;
+// Row-times-vector with the vector distributed one entry per lane (lane j holds u_j, S <= 32: DPP rows 0 and 1) and row i
+// of the matrix in the registers of lane i.  The vector reaches the other lanes as the DPP operand of the multiply-add
+// itself: v_permlane16_swap on (u, copy of u) leaves row 0's entries in both rows of one register and row 1's in both rows
+// of another, then entry j is `row_newbcast:j mod 16` of the one or the other -- S fused instructions and one lane swap.
+// (Measured per product at S = 21, cycles: v_readlane pairs as the compiler schedules them, through one scalar pair, 660;
+// the vector re-read from LDS by every lane 600; readlanes batched into distinct scalar registers 445; this form 250.)
+template <int J0, int J1, int J2>
+__device__ __forceinline__ void fma_bcast3(double& a0, double& a1, double& a2, const double s0, const double s1,
+                                           const double s2, const double k0, const double k1, const double k2) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0), "+v"(a1), "+v"(a2)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(k0), "v"(k1), "v"(k2), "n"(J0), "n"(J1), "n"(J2));
 }
-
-// The same product with the vector in LDS (every lane reads the whole vector: broadcast reads, conflict-free, all issued
-// before the first multiply-add).  The lane-read form above compiles to readlane pairs through ONE scalar register pair,
-// i.e. readlane, readlane, hazard nop, multiply-add strictly in turn (~30 cycles per entry); here the S multiply-adds
-// issue back to back once the reads land.  Same summation order: the two forms are bit-identical.
+template <int J0>
+__device__ __forceinline__ void fma_bcast1(double& a0, const double s0, const double k0) {
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+        : "+v"(a0) : "v"(s0), "v"(k0), "n"(J0));
+}
 template <int S>
-__device__ __forceinline__ double lds_matvec(const double (&kr)[S], const double* __restrict__ u) {
-    double uv[S];
-    static_for<0, S>([&](auto Jc) { uv[Jc] = u[Jc]; });
+__device__ __forceinline__ double dpp_matvec(const double (&kr)[S], const double u) {
+    static_assert(S <= 32, "the vector lives in DPP rows 0 and 1");
+    double d0, d1;
+    row_dup(u, d0, d1);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    static_for<0, S>([&](auto Jc) {
-        constexpr int j = Jc;
-        if constexpr (j % 3 == 0) a0 = fma(kr[j], uv[j], a0);
-        else if constexpr (j % 3 == 1) a1 = fma(kr[j], uv[j], a1);
-        else a2 = fma(kr[j], uv[j], a2);
+    static_for<0, S / 3>([&](auto Bc) {
+        constexpr int j = 3 * Bc;
+        fma_bcast3<j % 16, (j + 1) % 16, (j + 2) % 16>(a0, a1, a2, (j < 16) ? d0 : d1, (j + 1 < 16) ? d0 : d1,
+                                                       (j + 2 < 16) ? d0 : d1, kr[j], kr[j + 1], kr[j + 2]);
     });
+    if constexpr (S % 3 >= 1) fma_bcast1<(S - S % 3) % 16>(a0, (S - S % 3 < 16) ? d0 : d1, kr[S - S % 3]);
+    if constexpr (S % 3 == 2) fma_bcast1<(S - 1) % 16>(a1, (S - 1 < 16) ? d0 : d1, kr[S - 1]);
     return (a0 + a1) + a2;
 }
 
 // Krylov vectors PK[w][p] = K_w^p PK[w][0], p < npow, for the matrices in wmask at once: wave w owns K_w, lane i row i of
-// it in registers; a step is S lane reads of the previous vector and S multiply-adds (lane_matvec).  No block barrier inside (one
+// it in registers; a step is one lane swap and S fused DPP multiply-adds (dpp_matvec).  No block barrier inside (one
 // wave per chain); the caller synchronises before and after.
 template <int N, int TK>
 __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask) {
@@ -757,10 +759,10 @@ __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wma
         double kr[S];
         static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
         wave_sync();
+        double u = pk[li];                        // the start vector, one entry per lane
         for (int p = 1; p < npow; ++p) {
-            const double u = lds_matvec<S>(kr, pk + (p - 1) * NP);
+            u = dpp_matvec<S>(kr, u);
             if (lane < S) pk[p * NP + lane] = u;
-            wave_sync();
         }
     }
 }
@@ -942,21 +944,13 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
         double tprev = (li == 0) ? 1.0 : 0.0;     // T_0 e_0
         double tcur = kr[0];                      // T_1 e_0 = Khat e_0: column 0 = row 0 (symmetric), entry li
         double h = fma(cf[1], tcur, cf[0] * tprev);
-        wave_sync();                              // the sample buffer is free: it now carries T_i e_0, ping-pong
-        if (lane < S) vbuf[lane] = tcur;
-        wave_sync();
         for (int i = 2; i <= deg; ++i) {
-            const double* src = vbuf + (i & 1) * NP;
-            double* dst = vbuf + ((i & 1) ^ 1) * NP;
-            const double tnext = fma(2.0, lds_matvec<S>(kr, src), -tprev);
+            const double tnext = fma(2.0, dpp_matvec<S>(kr, tcur), -tprev);
             h = fma(cf[i], tnext, h);
-            if (lane < S) dst[lane] = tnext;
-            wave_sync();
             tprev = tcur; tcur = tnext;
         }
         if (deg < 1) h = cf[0] * tprev;
         if (lane < S) pk[lane] = h;
-        wave_sync();
         ND_STAMP(18);
 #ifdef MFS_ND_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[20] += deg;
@@ -964,18 +958,16 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
         // ---- powers of K itself: K u = half Khat u + mid u
         double u = h;
         for (int p = 1; p < npow; ++p) {
-            u = fma(half, lds_matvec<S>(kr, pk + (p - 1) * NP), mid * u);
+            u = fma(half, dpp_matvec<S>(kr, u), mid * u);
             if (lane < S) pk[p * NP + lane] = u;
-            wave_sync();
         }
         ND_STAMP(19);
     } else {
         if (lane < NP) pk[lane] = (lane == 0) ? 1.0 : 0.0;
-        wave_sync();
+        double u = (lane == 0) ? 1.0 : 0.0;
         for (int p = 1; p < npow; ++p) {
-            const double u = lds_matvec<S>(kr, pk + (p - 1) * NP);
+            u = dpp_matvec<S>(kr, u);
             if (lane < S) pk[p * NP + lane] = u;
-            wave_sync();
         }
     }
 }
