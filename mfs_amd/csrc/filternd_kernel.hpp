@@ -149,7 +149,12 @@ struct NdTile {
     static constexpr int kTermGroups = (4 * Z <= 256) ? 4 : (3 * Z <= 256) ? 3 : (2 * Z <= 256) ? 2 : 1;   // threads per moment
     static constexpr int kTermPad = kTermGroups * kTermChunk;   // the list is padded to a multiple of this with zero terms
     static constexpr int oFf = oTerms + ((TK == 0) ? (kMaxTermWords + kTermPad + 2) / 2 : 0);   // [P][5]
-    static constexpr int kDoubles = oFf + ((TK == 0) ? P * 5 : 0);
+    // gather indices of G, H_0, H_1 as u16 ([3][S][S]), when they fit next to the rest at two workgroups per CU: the
+    // per-rule gather then makes no global-memory round trip
+    static constexpr int oGi = oFf + ((TK == 0) ? P * 5 : 0);
+    static constexpr int nGi = (3 * S * S + 3) / 4;
+    static constexpr bool kGatherLds = (oGi + nGi) * 8 <= 80 * 1024;
+    static constexpr int kDoubles = oGi + (kGatherLds ? nGi : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
     // moment-array tiles (free while a Jacobi runs)
     static constexpr int oJs = (TK == 1) ? oW : oM;
@@ -266,9 +271,18 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
     for (int e = tid; e < NP * NP; e += nthr) {
         const int i = e / NP, j = e - i * NP;
         const bool in = (i < S) && (j < S);
-        A[i * LD + j] = in ? mom[inds[i * S + j]] : 0.0;
-        K[i * LD + j] = in ? mom[inds[S * S + i * S + j]] : 0.0;
-        K[NP * LD + i * LD + j] = in ? mom[inds[2 * S * S + i * S + j]] : 0.0;
+        const int o = in ? i * S + j : 0;
+        int g0, g1, g2;
+        if constexpr (L::kGatherLds) {
+            const unsigned short* gi = reinterpret_cast<const unsigned short*>(Sm + L::oGi);
+            g0 = gi[o]; g1 = gi[S * S + o]; g2 = gi[2 * S * S + o];
+        } else {
+            g0 = inds[o]; g1 = inds[S * S + o]; g2 = inds[2 * S * S + o];
+        }
+        const double v0 = mom[g0], v1 = mom[g1], v2 = mom[g2];
+        A[i * LD + j] = in ? v0 : 0.0;
+        K[i * LD + j] = in ? v1 : 0.0;
+        K[NP * LD + i * LD + j] = in ? v2 : 0.0;
     }
     if (tid == 0) flags[0] = 0.0;
     __syncthreads();
@@ -288,10 +302,21 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
             const int hc = (tid < 2 * S) ? tid : 0, hm = hc / S, hj = hc - hm * S;
             static_assert(S <= 32, "rows of L live in DPP rows 0 and 1");
             constexpr int S0 = (S < 16) ? S : 16;     // columns whose entries are needed from DPP row 0 (rows j < 16)
-            double Lr[S], xc[S];
+            // When 3 S <= 64 the rows of G (lanes 0 .. S-1) and the columns of [H_0 | H_1] (lanes S .. 3S-1) share ONE
+            // register array: elimination and forward substitution are the same instruction -- v[c] -= v[j] L[c][j] -- on
+            // different lanes, so one stream of fused DPP multiply-adds serves both (a third fewer than two streams).
+            constexpr bool kMerged = (3 * S <= 64);
+            const int xc_lane = kMerged ? ((tid >= S && tid < 3 * S) ? tid - S : 0) : hc;     // which column of [H_0 | H_1] this lane eliminates
+            const int xm = xc_lane / S, xj = xc_lane - xm * S;
+            const bool is_row = tid < S;
+            double Lr[S], xc[kMerged ? 1 : S];
             double* rinv_lds = Sm + L::oRed;          // 1 / L_jj, parked in LDS between the two solves (registers are short)
             double D0[S0], D1[(S > 16) ? S : 1];      // column k of L: DPP row 0 / DPP row 1 of it in all four rows
-            static_for<0, S>([&](auto Jc) { Lr[Jc] = A[li * LD + Jc]; xc[Jc] = K[hm * NP * LD + Jc * LD + hj]; });
+            static_for<0, S>([&](auto Jc) {
+                const double gv = A[li * LD + Jc], hv = K[xm * NP * LD + Jc * LD + xj];
+                if constexpr (kMerged) Lr[Jc] = is_row ? gv : hv;
+                else { Lr[Jc] = gv; xc[Jc] = hv; }
+            });
             bool bad = false;
             // right-looking: a final column is subtracted from every later column at once (blocks of eight fused DPP
             // multiply-adds behind one hazard nop, independent accumulators) -- each column still receives its terms in
@@ -299,13 +324,13 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
             constexpr int loE = (S < 16) ? S : 16;
             static_for<0, S>([&](auto Jc) {
                 constexpr int j = Jc;
-                const double s = Lr[j], xa = xc[j];
+                const double s = Lr[j];
                 const double pj = bcast<64, j>(s);
                 bad |= !(pj > 0.0);
                 const double rinv = rsq_nr(pj);
                 if (tid == 0) rinv_lds[j] = rinv;
                 Lr[j] = s * rinv;       // row j itself gets sqrt(piv) = piv * rinv
-                xc[j] = xa * rinv;
+                if constexpr (!kMerged) xc[j] = xc[j] * rinv;
                 if constexpr (j + 1 < S) {   // column j is final: spread its two DPP rows over the wave
                     double ev, od, lo, up;
                     row_dup(Lr[j], ev, od);
@@ -313,18 +338,21 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
                     if constexpr (S > 16) { half_dup(od, lo, up); D1[j] = lo; }
                     if constexpr (j + 1 < loE) {
                         fnma_bcast_range<j + 1, loE, 0>(Lr, Lr[j], D0[j]);
-                        fnma_bcast_range<j + 1, loE, 0>(xc, xc[j], D0[j]);
+                        if constexpr (!kMerged) fnma_bcast_range<j + 1, loE, 0>(xc, xc[j], D0[j]);
                     }
                     if constexpr (S > 16) {
                         constexpr int hi0 = (j + 1 > 16) ? j + 1 : 16;
                         fnma_bcast_range<hi0, S, 16>(Lr, Lr[j], D1[j]);
-                        fnma_bcast_range<hi0, S, 16>(xc, xc[j], D1[j]);
+                        if constexpr (!kMerged) fnma_bcast_range<hi0, S, 16>(xc, xc[j], D1[j]);
                     }
                 }
             });
             if (tid == 0 && bad) flags[0] = 1.0;
-            // transpose X through the K tiles: column hc of X_m -> K_m[:, hj]
-            static_for<0, S>([&](auto Jc) { if (tid < 2 * S) K[hm * NP * LD + Jc * LD + hj] = xc[Jc]; });
+            // transpose X through the K tiles: column xj of X_m -> K_m[:, xj]
+            static_for<0, S>([&](auto Jc) {
+                if constexpr (kMerged) { if (tid >= S && tid < 3 * S) K[xm * NP * LD + Jc * LD + xj] = Lr[Jc]; }
+                else { if (tid < 2 * S) K[xm * NP * LD + Jc * LD + xj] = xc[Jc]; }
+            });
             wave_sync();
             // row hj of X_m is column hj of X_m^T: forward-substitute it, K_m[hj][:] = (R^-1 X_m^T)[:, hj]
             double yr[S];
@@ -393,14 +421,17 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
     }
 
     ND_STAMP(1);
-    for (int e = tid; e < 2 * S * S; e += nthr) {
-        double* Kk = K + (e / (S * S)) * NP * LD;
-        const int f = e % (S * S), i = f / S, j = f - i * S;
-        if (i > j) {
-            const double s = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
-            Kk[i * LD + j] = s;
-            Kk[j * LD + i] = s;
-        }
+    constexpr int NPAIR = S * (S - 1) / 2;
+    for (int e = tid; e < 2 * NPAIR; e += nthr) {     // one (i > j) pair per item: pair f of the strict lower triangle, row by row
+        double* Kk = K + (e / NPAIR) * NP * LD;
+        const int f = e % NPAIR;
+        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)f)) * 0.5f);
+        i += ((i + 1) * i / 2 <= f) ? 1 : 0;
+        i -= (i * (i - 1) / 2 > f) ? 1 : 0;
+        const int j = f - i * (i - 1) / 2;
+        const double s = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
+        Kk[i * LD + j] = s;
+        Kk[j * LD + i] = s;
     }
     __syncthreads();
 
@@ -1030,6 +1061,10 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         }
         if (tid == 0) Sm[L::oQs + kNdTerms * DD6] = 0.0;
         for (int e = tid; e < P * 5; e += 256) Sm[L::oFf + e] = ffact(e / 5, e % 5) * ((e % 5 <= e / 5) ? 1.0 : 0.0);
+    }
+    if constexpr (L::kGatherLds) {
+        unsigned short* gi = reinterpret_cast<unsigned short*>(Sm + L::oGi);
+        for (int e = tid; e < 3 * S * S; e += 256) gi[e] = (unsigned short)a.inds[e];
     }
     if (tid < 8) {
         const double* src = a.lik + (a.lik_batched ? (size_t)b * a.n_factors * 4 : 0);
