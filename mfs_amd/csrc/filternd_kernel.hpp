@@ -922,18 +922,19 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
         // ---- Gershgorin interval
         double dmin, dmax;
         {
-            double rad = 0.0;
-            static_for<0, S>([&](auto Jc) { rad += fabs(kr[Jc]); });
-            double dg = 0.0;
-            static_for<0, S>([&](auto Jc) { if (Jc == li) dg = kr[Jc]; });
-            rad -= fabs(dg);
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+            static_for<0, S>([&](auto Jc) {
+                if constexpr (Jc % 3 == 0) r0 += fabs(kr[Jc]); else if constexpr (Jc % 3 == 1) r1 += fabs(kr[Jc]); else r2 += fabs(kr[Jc]);
+            });
+            const double dg = Kw[li];               // the diagonal entry of this lane's row (selecting it from the registers was 21 compare + select pairs)
+            const double rad = ((r0 + r1) + r2) - fabs(dg);
             double lo = (lane < S) ? dg - rad : 1.79e308, hi = (lane < S) ? dg + rad : -1.79e308;
             dmin = -wave_max64(-lo); dmax = wave_max64(hi);
         }
         const double mid = 0.5 * (dmin + dmax);
         double half = 0.5 * (dmax - dmin);
         half = (half > 0.0) ? half : 1.0;
-        const double ihalf = 1.0 / half;
+        const double ihalf = rcp_nr(half);        // (the interval only has to contain the spectrum; 1 ulp of its width is immaterial)
         ND_STAMP(16);
         // ---- f at the Chebyshev nodes (lanes < NCH), coefficients by the cosine table
         {
