@@ -775,11 +775,13 @@ __device__ __forceinline__ double dpp_matvec(const double (&kr)[S], const double
     return (a0 + a1) + a2;
 }
 
-// Krylov vectors PK[w][p] = K_w^p PK[w][0], p < npow, for the matrices in wmask at once: wave w owns K_w, lane i row i of
+// Krylov vectors PK[w][p] = (K_w - d_w I)^p PK[w][0], p < npow, for the matrices in wmask at once (d_w: the centre the
+// moments are wanted about, in units of lambda -- powers of the shifted matrix give the moments about the NEW mean directly,
+// where shifting the moment array afterwards took two more LDS-bound passes): wave w owns K_w, lane i row i of
 // it in registers; a step is one lane swap and S fused DPP multiply-adds (dpp_matvec).  No block barrier inside (one
 // wave per chain); the caller synchronises before and after.
 template <int N, int TK>
-__device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask) {
+__device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask, const double d0, const double d1) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW;
     const int tid = threadIdx.x;
@@ -787,23 +789,24 @@ __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wma
         const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
         const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
         double* pk = Sm + L::oPK + w * NPW * NP;
+        const double d = w ? d1 : d0;
         double kr[S];
         static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
         wave_sync();
         double u = pk[li];                        // the start vector, one entry per lane
         for (int p = 1; p < npow; ++p) {
-            u = dpp_matvec<S>(kr, u);
+            u = fma(-d, u, dpp_matvec<S>(kr, u));
             if (lane < S) pk[p * NP + lane] = u;
         }
     }
 }
 
-// M[p][q] = sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow with p + q <= maxdeg (the only entries any later stage
+// M[p][q] = fac sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow with p + q <= maxdeg (the only entries any later stage
 // reads; the rest are zeroed): the moments sum_ij W_ij xi0_i^p xi1_j^q of the rule about its own centre
 // (xi = x - mean = scale * lambda).
 template <int N, int TK>
 __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const int maxdeg, const double sc0,
-                                    const double sc1) {
+                                    const double sc1, const double fac) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD;
     const double* p0 = Sm + L::oPK;
@@ -822,7 +825,7 @@ __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, con
                 else if constexpr (j % 3 == 1) a1 = fma(u[j], w[j], a1);
                 else a2 = fma(u[j], w[j], a2);
             });
-            double f = 1.0;
+            double f = fac;
             for (int k = 0; k < p; ++k) f *= sc0;
             for (int k = 0; k < q; ++k) f *= sc1;
             v = ((a0 + a1) + a2) * f;
@@ -898,11 +901,11 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
 //   nodes      lambda_j = mid + half cos(pi (j + 1/2) / NCH)
 //   c_i        = (2 - [i = 0]) / NCH sum_j f(lambda_j) cos(pi i (j + 1/2) / NCH)
 //   h          = sum_i c_i T_i(Khat) e_0,   Khat = (K - mid) / half,  T_{i+1} = 2 Khat T_i - T_{i-1}
-// followed in the same wave by the powers PK[k][p] = K^p h, p < npow.  Wave k works on matrix k (lane i = row i); waves
-// whose component no factor reads run the plain Krylov recurrence from e_0.  No block barrier inside.
+// followed in the same wave by K h.  Wave k works on matrix k (lane i = row i); for a component no factor reads h = e_0.
+// Leaves PK[k][0] = h_k, PK[k][1] = K_k h_k.  No block barrier inside.
 template <int N, int TK>
-__device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, const int npow, const int lik_mask,
-                               const double* __restrict__ ysrow, const double mean0, const double mean1,
+__device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const int lik_mask,
+                          const double* __restrict__ ysrow, const double mean0, const double mean1,
                                const double scale0, const double scale1) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW, NCH = L::NCH;
@@ -987,20 +990,17 @@ __device__ void cheb_krylov_nd(double* __restrict__ Sm, const FilterNdArgs& a, c
 #ifdef MFS_ND_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[20] += deg;
 #endif
-        // ---- powers of K itself: K u = half Khat u + mid u
-        double u = h;
-        for (int p = 1; p < npow; ++p) {
-            u = fma(half, dpp_matvec<S>(kr, u), mid * u);
-            if (lane < S) pk[p * NP + lane] = u;
+        // ---- K h as well (K u = half Khat u + mid u): with h it gives p_y and the posterior mean, about which the caller
+        //      then takes the powers
+        {
+            const double u = fma(half, dpp_matvec<S>(kr, h), mid * h);
+            if (lane < S) pk[NP + lane] = u;
         }
         ND_STAMP(19);
     } else {
         if (lane < NP) pk[lane] = (lane == 0) ? 1.0 : 0.0;
-        double u = (lane == 0) ? 1.0 : 0.0;
-        for (int p = 1; p < npow; ++p) {
-            u = dpp_matvec<S>(kr, u);
-            if (lane < S) pk[p * NP + lane] = u;
-        }
+        const double u = dpp_matvec<S>(kr, (lane == 0) ? 1.0 : 0.0);
+        if (lane < S) pk[NP + lane] = u;
     }
 }
 
@@ -1107,15 +1107,21 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 double c0 = 0.0, c1 = 0.0, ns0 = 1.0, ns1 = 1.0;
                 if constexpr (TK == 0) {
                     ND_STAMP_BEGIN;
-                    // ---- Krylov vectors from e_0 and the moment array of the rule about its own centre
+                    // ---- the low corner of the rule's moment array about its own centre: all that the new means (and
+                    //      scales) need -- a few Krylov steps from e_0
                     const int npow = P + a.D - 1;
+                    int nlow = 2;     // extents of the blocks that are summed over the rule: mean rows, variance rows
+                    for (int r4 = 0; r4 < (scaled ? 4 : 2); ++r4) {
+                        const int row = (r4 < 2) ? r4 : 12 + r4;
+                        nlow = max(nlow, max(a.ext[row] & 0xff, a.ext[row] >> 8));
+                    }
                     if (tid < 2 * NP) Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
                     __syncthreads();
-                    krylov_nd<N, TK>(Sm, npow, 3);
+                    krylov_nd<N, TK>(Sm, nlow, 3, 0.0, 0.0);
                     __syncthreads();
                     ND_STAMP(10);
                     const int maxdeg = P - 1 + 2 * (a.D - 1);     // highest total degree a re-centred block reaches from a moment
-                    bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1);
+                    bilinear_moments_nd<N, TK>(Sm, nlow, 2 * (nlow - 1), scale0, scale1, 1.0);
                     __syncthreads();
                     ND_STAMP(11);
                     // ---- sums of the mean rows (and, scaled mode, the variance rows) of the table over the rule: each is a
@@ -1153,13 +1159,17 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     if (!raw) { c0 = mean0 + M[1 * MLD + 0] + bx[DD6 + 0]; c1 = mean1 + M[0 * MLD + 1] + bx[DD6 + 1]; }
                     if (scaled) { ns0 = sqrt(bx[DD6 + 2]); ns1 = sqrt(bx[DD6 + 3]); }
                     ND_STAMP(12);
-                    // ---- coefficient blocks re-centred at the new mean: Q_kappa(c + eta) in powers of eta, one packed term
-                    //      (kappa, alpha, beta) per thread
-                    {
+                    // ---- waves 0, 1: Krylov vectors of the matrices shifted to the NEW mean; meanwhile waves 2, 3: the coefficient
+                    //      blocks re-centred there, Q_kappa(c + eta) in powers of eta, one packed term (kappa, alpha, beta) per
+                    //      thread and pass
+                    __syncthreads();     // (everybody has read bx and the low corner of M)
+                    if (tid < 128) {
+                        krylov_nd<N, TK>(Sm, npow, 3, (c0 - mean0) / scale0, (c1 - mean1) / scale1);
+                    } else {
                         const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
                         const int nt = (int)tw[0];
                         const double* bin = Sm + L::oBin;
-                        for (int e = tid; e < nt; e += 256) {
+                        for (int e = tid - 128; e < nt; e += 128) {
                             const unsigned w = tw[1 + e];
                             const int al = (w >> 6) & 7, be = (w >> 9) & 7, ea = (w >> 12) & 7, eb = (w >> 15) & 7, qi = w >> 18;
                             const double* blk = coef + (qi / DD6) * DD;
@@ -1173,9 +1183,11 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                             qs[qi] = acc;
                         }
                     }
-                    // ---- the moment array about the new mean
+                    __syncthreads();
                     ND_STAMP(13);
-                    shift_moments_nd<N, TK, NPW - 1>(Sm, npow, maxdeg, c0 - mean0, c1 - mean1, 1.0);   // (barriers inside; qs is complete after them)
+                    // ---- the moment array about the new mean
+                    bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1, 1.0);
+                    __syncthreads();
                     ND_STAMP(14);
                     // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)],
                     //      the kappa terms of a moment spread over four threads (partial sums through the free M2 tile)
@@ -1356,13 +1368,16 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             {
                 const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
                 bad = bad || poisoned;
-                // h_k = lik_k(X_k) e_0 and the powers K_k^p h_k: Chebyshev evaluation (no eigen-decomposition), checked;
-                // cyclic Jacobi + spectral evaluation only if the coefficients of some factor have not converged
+                // h_k = lik_k(X_k) e_0 and K_k h_k: Chebyshev evaluation (no eigen-decomposition), checked; they give p_y and the
+                // posterior mean, and the powers of the matrices shifted THERE give the posterior central moments directly.
+                // Cyclic Jacobi + spectral evaluation (and a binomial shift of the moment array) only if the coefficients of
+                // some factor have not converged.
                 ND_STAMP_BEGIN;
                 if (tid == 0) Sm[L::oMisc + 6] = 0.0;
                 __syncthreads();
-                cheb_krylov_nd<N, TK>(Sm, a, P, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
+                cheb_h_nd<N, TK>(Sm, a, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
                 __syncthreads();
+                double c0 = 0.0, c1 = 0.0;
                 if (MFS_ND_FORCE_JACOBI || a.force_eigen || Sm[L::oMisc + 6] != 0.0) {
                     jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
                     warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
@@ -1409,19 +1424,38 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                         if constexpr (S & 1) a0 = fma(Vr[S - 1], gl[S - 1], a0);
                         Sm[L::oPK + (k * NPW + p) * NP + r] = a0 + a1;
                     }
-                    krylov_nd<N, TK>(Sm, P, 3 & ~lik_mask);
+                    krylov_nd<N, TK>(Sm, P, 3 & ~lik_mask, 0.0, 0.0);
+                    __syncthreads();
+                    ND_STAMP(15);
+                    bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, 1.0);
+                    __syncthreads();
+                    const double py = M[0];
+                    const double ipy = 1.0 / py;
+                    if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
+                    nell -= fast_log(py);
+                    __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
+                    shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
+                } else {
+                    // p_y = h_0 . h_1 and the first moments (K_0 h_0) . h_1, h_0 . (K_1 h_1): every wave forms them itself (lane
+                    // products and three wave sums), so no broadcast is needed
+                    const int lane = tid & 63;
+                    const double* p0 = Sm + L::oPK;
+                    const double* p1 = Sm + L::oPK + NPW * NP;
+                    const bool in = lane < S;
+                    const double h0 = in ? p0[lane] : 0.0, u0 = in ? p0[NP + lane] : 0.0;
+                    const double h1 = in ? p1[lane] : 0.0, u1 = in ? p1[NP + lane] : 0.0;
+                    const double py = wave_sum64(h0 * h1), a10 = wave_sum64(u0 * h1), a01 = wave_sum64(h0 * u1);
+                    const double ipy = 1.0 / py;
+                    const double dl0 = raw ? 0.0 : a10 * ipy, dl1 = raw ? 0.0 : a01 * ipy;      // posterior mean - mean, in units of lambda
+                    if (!raw) { c0 = fma(scale0, dl0, mean0); c1 = fma(scale1, dl1, mean1); }
+                    nell -= fast_log(py);
+                    __syncthreads();   // (everybody has read PK[.][1] before the powers overwrite it)
+                    krylov_nd<N, TK>(Sm, P, 3, dl0, dl1);
+                    __syncthreads();
+                    ND_STAMP(15);
+                    bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, ipy);
                     __syncthreads();
                 }
-                ND_STAMP(15);
-                bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1);
-                __syncthreads();
-                const double py = M[0];
-                const double ipy = 1.0 / py;
-                double c0 = 0.0, c1 = 0.0;
-                if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
-                nell -= fast_log(py);
-                __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
-                shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
                 for (int zi = tid; zi < Z; zi += 256) {

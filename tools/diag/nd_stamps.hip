@@ -4,7 +4,8 @@
 #include <cstdio>
 #include <vector>
 using namespace mfs;
-int main(int argc, char** argv) {
+template <int TK>
+int run(int argc, char** argv) {
     constexpr int N = 6;
     FILE* f = fopen(argv[1], "rb");
     int hdr[6]; fread(hdr, 4, 6, f);  // T, B, D, n_terms, z, s
@@ -22,18 +23,18 @@ int main(int argc, char** argv) {
     FilterNdArgs a{}; a.mode = 1; a.T = T; a.B = B; a.stable = 0; a.n_terms_used = nt; a.D = D; a.n_factors = 1; a.ny = 1;
     a.fac_kind[0] = 0; a.fac_comp[0] = 0; a.fac_ycol[0] = 0; for (int k = 0; k < kNdRows; ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
     a.out_mom = nullptr; a.out_mean = dmeans; a.out_nell = dnell; a.out_first_nan = nullptr;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    constexpr int lds = NdTile<N, 0>::kDoubles * 8;
-    hipLaunchKernelGGL((filternd_kernel<N, 0>), dim3(B), dim3(256), lds, 0, a);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    constexpr int lds = NdTile<N, TK>::kDoubles * 8;
+    hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(B), dim3(256), lds, 0, a);
     hipDeviceSynchronize();
     unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
     const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
     double tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
     printf("steps %llu, Jacobi sweeps %llu (%.2f per update rule; one matrix)\n", st[9], st[8], (double)st[8] / st[9]);
     for (int i = 0; i < 8; ++i) printf("%-24s %10.0f cycles per step  %5.1f %%\n", names[i], (double)st[i] / st[9], 100.0 * st[i] / tot);
-    const char* sub[] = {"  predict: krylov", "  predict: moment array", "  predict: means", "  predict: re-centred coefficients", "  predict: shift", "  update: Chebyshev h + powers (or Jacobi)"};
+    const char* sub[] = {"  predict: Krylov, low corner", "  predict: moment array, low corner", "  predict: means", "  predict: Krylov at new mean || re-centring", "  predict: moment array", "  update: h, K h, means, shifted powers"};
     for (int i = 0; i < 6; ++i) printf("%-36s %10.0f cycles per step\n", sub[i], (double)st[10 + i] / st[9]);
-    const char* sub2[] = {"    cheb: Gershgorin", "    cheb: samples + coefficients", "    cheb: recurrence", "    cheb: powers"};
+    const char* sub2[] = {"    cheb: Gershgorin", "    cheb: samples + coefficients", "    cheb: recurrence", "    cheb: K h"};
     for (int i = 0; i < 4; ++i) printf("%-36s %10.0f cycles per step\n", sub2[i], (double)st[16 + i] / st[9]);
     printf("    mean Chebyshev degree %.1f\n", (double)st[20] / st[9]);
     unsigned long long hist[8][40]; hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_nd_hist), sizeof(hist));
@@ -47,3 +48,4 @@ int main(int argc, char** argv) {
     std::vector<double> nell(B); hipMemcpy(nell.data(), dnell, B * 8, hipMemcpyDeviceToHost); printf("nell[0] = %.10f\n", nell[0]);
     return 0;
 }
+int main(int argc, char** argv) { return (argc > 2 && argv[2][0] == '1') ? run<1>(argc, argv) : run<0>(argc, argv); }
