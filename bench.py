@@ -491,8 +491,7 @@ def main():
         print(json.dumps(out), flush=True)
     else:
         w.release()
-    if world > 1 and not gather_ok and not args.allow_host_gather:
-        exit_code = dist.EXIT_RCCL_FAILED
+    exit_code = comm.exit_status(gather_ok, args.allow_host_gather)
     comm.close()
     sys.exit(exit_code)
 

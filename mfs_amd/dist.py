@@ -135,6 +135,13 @@ class Communicator:
         """True when a multi-rank run asked for the RCCL data path and is not on it (see `rccl_error`)."""
         return self.world > 1 and self.rccl_error is not None
 
+    def exit_status(self, gather_ok: bool = True, allow_host_gather: bool = False) -> int:
+        """Process exit status of a run on this communicator: `EXIT_RCCL_FAILED` for a multi-rank run whose NLL gather did
+        not go through RCCL (or did not reproduce the ranks' values), unless the caller accepted the host route."""
+        if self.world > 1 and (self.degraded or not gather_ok) and not allow_host_gather:
+            return EXIT_RCCL_FAILED
+        return 0
+
     # -- control plane (host)
     def barrier(self):
         if self._rdzv is not None:

@@ -83,3 +83,42 @@ def test_two_rank_sharding_and_allgather(tmp_path, kw, port):
     ys, _ = synth.benes_bernoulli_batch(B, T, odt, seed=3)
     ref = np.array([o.moment_filter_cms(fns[1], fns[3], opmf, oic.cms, oic.mean, y)[2] for y in ys])
     np.testing.assert_allclose(r0[:5], ref, rtol=1e-13)
+
+
+FAIL_WORKER = textwrap.dedent('''
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    from mfs_amd import dist
+    comm = dist.Communicator.from_env(control='tcp', data='rccl')      # what bench.py asks for; there is no GPU here
+    gathered = comm.allgather_host(np.array([float(comm.rank)]))          # the host route still works ...
+    status = comm.exit_status(gather_ok=True, allow_host_gather=%(allow)r)
+    with open(os.path.join(%(out)r, f'rank{comm.rank}.json'), 'w') as f:
+        json.dump({'degraded': comm.degraded, 'data': comm.data, 'error': comm.rccl_error, 'gathered': gathered.tolist(),
+                   'status': status}, f)
+    comm.close()
+    sys.exit(status)                                                      # ... but the run does not count as a success
+''')
+
+
+@pytest.mark.parametrize('allow,expected', [(False, dist.EXIT_RCCL_FAILED), (True, 0)])
+def test_multi_rank_run_without_rccl_is_a_visible_failure(tmp_path, allow, expected):
+    """VERDICT r1 item 7: with WORLD_SIZE > 1, a run whose NLL gather cannot go through RCCL (here: no GPU at all) says so
+    -- `degraded`, an error text, exit status 3 on every rank -- and still delivers the gather through host memory; only
+    an explicit --allow-host-gather turns that into status 0."""
+    import json
+    script = tmp_path / 'worker.py'
+    script.write_text(FAIL_WORKER % {'root': ROOT, 'out': str(tmp_path), 'allow': allow})
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29547', MFS_RCCL_INIT_TIMEOUT='30',
+                   HIP_VISIBLE_DEVICES='')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    codes = [p.wait(timeout=180) for p in procs]
+    assert codes == [expected, expected], [p.stderr.read().decode()[-400:] for p in procs]
+    for rank in range(2):
+        r = json.load(open(tmp_path / f'rank{rank}.json'))
+        assert r['degraded'] is True and r['data'] == 'host' and r['error']
+        assert r['gathered'] == [0.0, 1.0]
+        assert r['status'] == expected
