@@ -232,11 +232,12 @@ int mfs_elementary(int which, int n, const double* x, double* out, int device);
  * 210-280, 33-207) for B replicates, with either transition family the reference offers.
  *
  * MFS_ND_TRANS_OPERATOR ('multi-index' signature, sde_cond_moments_tme, mfs/multi_dims/moments.py:414-479):
- * polynomial drift / dispersion reduced on the host to the operator table Q_kappa(x), 1 <= |kappa| <= 4
- * (TME order <= 2), dense per-variable extent D: coef [MFS_ND_TERMS][D][D] in graded-lex kappa order
- * (0,1),(1,0),(0,2),(1,1),(2,0),(0,3),...,(4,0), zeros where the model has no term.  Conditional mean_k = x_k + Q_{e_k}.
- * Rows 14, 15 hold the conditional variances of X'_0, X'_1 (diagonal of tme.mean_and_cov, moments.py:469-476), read in
- * scaled mode only.
+ * polynomial drift / dispersion reduced on the host to the operator table Q_kappa(x), 1 <= |kappa| <= 2 M for TME order
+ * M <= 3, dense per-variable extent D, in graded-lex kappa order (0,1),(1,0),(0,2),(1,1),(2,0),(0,3),..., zeros where the
+ * model has no term.  Conditional mean_k = x_k + Q_{e_k}.  Two layouts, chosen by n_terms (MFS_ND_TABLE_ROWS):
+ *   n_terms <= MFS_ND_TERMS (|kappa| <= 4, TME order <= 2): coef [16][D][D], rows 14, 15 the conditional variances of
+ *     X'_0, X'_1 (diagonal of tme.mean_and_cov, moments.py:469-476; read in scaled mode only);
+ *   n_terms <= MFS_ND_TERMS_MAX (|kappa| <= 6, TME order 3): coef [29][D][D], rows 27, 28 the variances.
  *
  * MFS_ND_TRANS_GAUSSIAN ('index' signature, the Normal closures sde_cond_moments_tme_normal / _euler_maruyama,
  * mfs/multi_dims/moments.py:340-411, 257-337, whose moments the reference takes from Kan's formula, :110-154):
@@ -256,9 +257,13 @@ int mfs_elementary(int which, int n, const double* x, double* out, int device);
  *   out_moments [B][T][z]; out_means [B][T][2] (central, scaled; NULL in raw mode); out_scales [B][T][2] (scaled);
  *   out_nell [B]; out_first_nan [B]
  */
-#define MFS_ND_TERMS 14
-#define MFS_ND_ROWS 16 /* coefficient blocks passed: MFS_ND_TERMS operator terms + 2 variance rows */
-#define MFS_ND_MAX_EXTENT 6
+#define MFS_ND_TERMS 14     /* kappa terms with |kappa| <= 4 */
+#define MFS_ND_TERMS_MAX 27 /* ... with |kappa| <= 6 */
+#define MFS_ND_ROWS 16      /* coefficient blocks of the short layout: MFS_ND_TERMS operator terms + 2 variance rows */
+#define MFS_ND_ROWS_MAX 29
+#define MFS_ND_TABLE_ROWS(n_terms) ((n_terms) > MFS_ND_TERMS ? MFS_ND_ROWS_MAX : MFS_ND_ROWS)
+#define MFS_ND_MAX_EXTENT 6    /* per-variable extent (degree + 1) of the coefficient blocks, short layout */
+#define MFS_ND_MAX_EXTENT_HI 7 /* ... long layout (TME order 3 of a quadratic drift reaches degree 6) */
 #define MFS_ND_MAX_FACTORS 2
 #define MFS_ND_TRANS_OPERATOR 0
 #define MFS_ND_TRANS_GAUSSIAN 1
@@ -266,8 +271,8 @@ typedef struct mfs_model_nd {
     int32_t d;             /* 2 (d = 1 problems go through the 1-D entry points, which the reference guarantees equal:
                               tests/test_filtering.py:304-329; mfs_amd.multi_dims.filtering routes them) */
     int32_t trans_kind;    /* MFS_ND_TRANS_* */
-    int32_t n_terms;       /* MFS_ND_ROWS blocks are always passed; operator terms >= n_terms are known to be zero */
-    int32_t extent;        /* D <= MFS_ND_MAX_EXTENT */
+    int32_t n_terms;       /* MFS_ND_TABLE_ROWS(n_terms) blocks are passed; operator terms >= n_terms are known to be zero */
+    int32_t extent;        /* D <= MFS_ND_MAX_EXTENT (MFS_ND_MAX_EXTENT_HI with the long layout) */
     int32_t n_factors;     /* 1 .. MFS_ND_MAX_FACTORS likelihood factors */
     int32_t ny;            /* measurement columns per step (1 or 2) */
     int32_t fac_kind[MFS_ND_MAX_FACTORS];      /* MFS_LIK_* */
@@ -276,7 +281,7 @@ typedef struct mfs_model_nd {
     int32_t fac_n_par[MFS_ND_MAX_FACTORS];     /* parameters used (<= MFS_MAX_LIK) */
     int32_t coef_batched;  /* 0: one table; 1: one per replicate (per-replicate drift / dispersion parameters) */
     int32_t lik_batched;   /* likewise for the likelihood parameters */
-    const double* coef;    /* [MFS_ND_ROWS][D][D] or [B][MFS_ND_ROWS][D][D] */
+    const double* coef;    /* [rows][D][D] or [B][rows][D][D], rows = MFS_ND_TABLE_ROWS(n_terms) */
     const double* lik;     /* [n_factors][MFS_MAX_LIK] or [B][n_factors][MFS_MAX_LIK], unused entries 0 */
 } mfs_model_nd;
 

@@ -35,15 +35,23 @@ class MfsModelNd(C.Structure):
                 ('coef_batched', C.c_int32), ('lik_batched', C.c_int32), ('coef', c_double_p), ('lik', c_double_p)]
 
 
-ND_TERMS = 14
+ND_TERMS = 14          # kappa terms with |kappa| <= 4 (TME order <= 2): the 16-row table layout
 ND_ROWS = 16
+ND_TERMS_MAX = 27      # ... |kappa| <= 6 (TME order 3): the 29-row layout
+ND_ROWS_MAX = 29
 ND_TRANS_OPERATOR, ND_TRANS_GAUSSIAN = 0, 1
 ND_MAX_EXTENT = 6
+ND_MAX_EXTENT_HI = 7
 ND_MAX_FACTORS = 2
 MAX_LIK = 4
 ABI_VERSION = 2
-# derivative multi-indices kappa, 1 <= |kappa| <= 4, graded-lex (the order of mfs_model_nd.coef rows)
-ND_KAPPAS = [(a, s - a) for s in range(1, 5) for a in range(s + 1)]
+# derivative multi-indices kappa, 1 <= |kappa| <= 6, graded-lex (the order of mfs_model_nd.coef rows; the first 14 are |kappa| <= 4)
+ND_KAPPAS = [(a, s - a) for s in range(1, 7) for a in range(s + 1)]
+
+
+def nd_table_rows(n_terms: int) -> int:
+    """MFS_ND_TABLE_ROWS of include/mfs_hip.h."""
+    return ND_ROWS_MAX if n_terms > ND_TERMS else ND_ROWS
 
 
 class MfsError(RuntimeError):

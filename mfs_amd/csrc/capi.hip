@@ -22,7 +22,7 @@ Filter1dFastLaunch g_fast_filter_wide[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch, launch_gauss; int S, Z, lds_bytes; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
 hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s);
 extern Filter1dGradLaunch g_grad_table[11][5];  // filter1d_grad_inst.hip: [N <= 10][P <= 4]
@@ -680,6 +680,7 @@ int mfs_memcpy_d2d(void* dst, const void* src, uint64_t bytes, void* stream) {
 // ---------------------------------------------------------------------------------------------------------------
 struct mfs_plan_nd {
     int mode, N, T, B, stable, device, trans_kind, ny;
+    bool hi_terms = false;    // operator table with |kappa| > 4 terms (TME order 3): the 29-row layout and its kernel
     mfs::FilterNdArgs args;   // model part filled at create (device pointers), data pointers per run
     double* d_coef = nullptr;
     double* d_lik = nullptr;
@@ -709,10 +710,12 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
         return fail(MFS_EINVAL, "unknown N-D transition kind %d", model->trans_kind);
     if (model->trans_kind == MFS_ND_TRANS_GAUSSIAN && model->n_terms != 5)
         return fail(MFS_EINVAL, "the Gaussian N-D transition carries 5 polynomials (mu_0, mu_1, S_00, S_01, S_11)");
-    if (model->n_terms < 0 || model->n_terms > MFS_ND_TERMS) return fail(MFS_EINVAL, "bad n_terms %d", model->n_terms);
+    if (model->n_terms < 0 || model->n_terms > MFS_ND_TERMS_MAX) return fail(MFS_EINVAL, "bad n_terms %d", model->n_terms);
+    const int n_rows = MFS_ND_TABLE_ROWS(model->n_terms);     // 16, or 29 when terms with |kappa| > 4 are present (TME order 3)
     if (z != ke.Z) return fail(MFS_EINVAL, "The size of multi_indices %d must match that of the moments %d.", z, ke.Z);
-    if (model->extent < 1 || model->extent > MFS_ND_MAX_EXTENT)
-        return fail(MFS_EUNSUPPORTED, "coefficient extent %d outside [1, %d]", model->extent, MFS_ND_MAX_EXTENT);
+    const int max_extent = (model->trans_kind == MFS_ND_TRANS_OPERATOR && model->n_terms > MFS_ND_TERMS) ? MFS_ND_MAX_EXTENT_HI : MFS_ND_MAX_EXTENT;
+    if (model->extent < 1 || model->extent > max_extent)
+        return fail(MFS_EUNSUPPORTED, "coefficient extent %d outside [1, %d]", model->extent, max_extent);
     if (model->n_factors < 1 || model->n_factors > MFS_ND_MAX_FACTORS)
         return fail(MFS_EINVAL, "n_factors %d outside [1, %d]", model->n_factors, MFS_ND_MAX_FACTORS);
     if (model->ny < 1 || model->ny > 2) return fail(MFS_EINVAL, "ny %d outside [1, 2]", model->ny);
@@ -732,9 +735,9 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
     mfs_plan_nd* p = new (std::nothrow) mfs_plan_nd();
     if (!p) return fail(MFS_ENOMEM, "out of host memory");
     p->mode = mode; p->N = N; p->T = T; p->B = B; p->stable = stable; p->device = device;
-    p->trans_kind = model->trans_kind; p->ny = model->ny;
+    p->trans_kind = model->trans_kind; p->ny = model->ny; p->hi_terms = (model->trans_kind == MFS_ND_TRANS_OPERATOR && model->n_terms > MFS_ND_TERMS);
     const size_t S = ke.S, DD = (size_t)model->extent * model->extent;
-    const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * MFS_ND_ROWS * DD;
+    const size_t ncoef = (size_t)(model->coef_batched ? B : 1) * n_rows * DD;
     const size_t nlik = (size_t)(model->lik_batched ? B : 1) * model->n_factors * MFS_MAX_LIK;
     mfs::BlockPool<false>& pool = mfs::device_state(device).device;
     hipError_t e = pool.acquire((void**)&p->d_coef, ncoef * 8);
@@ -759,10 +762,10 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
     if (const char* e = getenv("MFS_ND_UPDATE")) a.force_eigen = (strcmp(e, "eigen") == 0);   // A/B switch, like MFS_SOLVER
     // true extents of each coefficient block (trailing zero rows / columns cut); the union over replicates when batched
     const size_t ntab = model->coef_batched ? (size_t)B : 1;
-    for (int k = 0; k < MFS_ND_ROWS; ++k) {
+    for (int k = 0; k < n_rows; ++k) {
         int ea = 0, eb = 0;
         for (size_t r = 0; r < ntab; ++r) {
-            const double* blk = model->coef + (r * MFS_ND_ROWS + k) * DD;
+            const double* blk = model->coef + (r * n_rows + k) * DD;
             for (int i = 0; i < model->extent; ++i)
                 for (int j = 0; j < model->extent; ++j)
                     if (blk[i * model->extent + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; }
@@ -790,7 +793,7 @@ extern "C" int mfs_plan_nd_run(mfs_plan_nd* p, const double* d_m0, int m0_batche
     a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
     a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
     const mfs::NdEntry& ke = mfs::g_nd_table[p->N];
-    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : ke.launch)(a, p->B, (hipStream_t)stream);
+    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : p->hi_terms ? ke.launch_hi : ke.launch)(a, p->B, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MFS_EHIP, "mfs_plan_nd_run: %s", hipGetErrorString(e));
     return MFS_OK;
 }

@@ -1,12 +1,12 @@
-// filternd_inst.hip -- instantiates the d = 2 N-D kernels for quadrature orders 2..7, both transition families
-// (TK = 0 operator table, TK = 1 Normal closure), and registers their launchers.
+// filternd_inst.hip -- instantiates the d = 2 N-D kernels for quadrature orders 2..7 and the transition families
+// (TK = 0 operator table with |kappa| <= 4, TK = 2 with |kappa| <= 6, TK = 1 Normal closure), and registers their launchers.
 #include "filternd_kernel.hpp"
 #include "launch_util.hpp"
 
 namespace mfs {
 
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch, launch_gauss; int S, Z, lds_bytes; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes; };
 NdEntry g_nd_table[8];
 
 template <int N, int TK>
@@ -19,8 +19,9 @@ hipError_t launch_nd(const FilterNdArgs& a, int grid, hipStream_t s) {
 
 template <int N>
 void reg_nd() {
-    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, NdTile<N, 0>::S, NdTile<N, 0>::Z,
-                            (NdTile<N, 0>::kDoubles > NdTile<N, 1>::kDoubles ? NdTile<N, 0>::kDoubles : NdTile<N, 1>::kDoubles) * 8};
+    constexpr int d0 = NdTile<N, 0>::kDoubles, d1 = NdTile<N, 1>::kDoubles, d2 = NdTile<N, 2>::kDoubles;
+    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, &launch_nd<N, 2>, NdTile<N, 0>::S, NdTile<N, 0>::Z,
+                            (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) * 8};
     if constexpr (N < 7) reg_nd<N + 1>();
 }
 

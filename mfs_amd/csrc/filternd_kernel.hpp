@@ -50,9 +50,10 @@ struct FilterNdArgs {
     int fac_kind[2], fac_comp[2], fac_ycol[2];
     int coef_batched, lik_batched;
     int force_eigen;          // 1: every update diagonalises K_k (the checked fallback of the Chebyshev evaluation, as the only route)
-    int ext[16];              // per-block true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
-    const double* coef;       // [kNdRows][D][D] (or [B][...]): rows 0..13 Q_kappa in the fixed kappa order below (zeros
-                              // where the model has no term), rows 14, 15 the conditional variances of X'_0, X'_1 (scaled mode)
+    int ext[32];              // per-block true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
+    const double* coef;       // [rows][D][D] (or [B][...]), rows = terms + 2 with terms = 14 or 27 (see nd_terms): Q_kappa in the
+                              // fixed kappa order below (zeros where the model has no term), then the conditional variances
+                              // of X'_0, X'_1 (scaled mode)
     const double* lik;        // [n_factors][4] (or [B][n_factors][4])
     const int32_t* inds;      // [3][s][s]
     const double* m0;         // [z] or [B][z]
@@ -67,9 +68,13 @@ struct FilterNdArgs {
     int32_t* out_first_nan;
 };
 
-// derivative multi-indices kappa with 1 <= |kappa| <= 4, graded-lex order (the order the host fills `coef` in)
-constexpr int kNdTerms = 14;
-constexpr int kNdRows = 16;
+// derivative multi-indices kappa, graded-lex order (the order the host fills `coef` in): 1 <= |kappa| <= 4 (TME order <= 2:
+// 14 terms, TK = 0) or <= 6 (TME order 3: 27 terms, TK = 2).  The coefficient table has two more rows, the conditional
+// variances of X'_0, X'_1 (scaled mode).  TK = 1 (Normal closure) uses rows 0..4 of the short layout.
+constexpr int kNdTermsLo = 14, kNdTermsHi = 27;
+template <int TK> constexpr int nd_terms() { return (TK == 2) ? kNdTermsHi : kNdTermsLo; }
+template <int TK> constexpr int nd_rows() { return nd_terms<TK>() + 2; }
+template <int TK> constexpr int nd_kmax() { return (TK == 2) ? 6 : 4; }      // highest derivative order per variable
 #ifndef MFS_ND_JACOBI_TOL
 #define MFS_ND_JACOBI_TOL 1e-31
 #endif
@@ -83,9 +88,9 @@ constexpr double kNdJacobiTol = MFS_ND_JACOBI_TOL;
 #endif
 // squared Frobenius size of the first-order eigenvector correction below which it replaces further sweeps (0: never)
 constexpr double kNdFinishX2 = MFS_ND_FINISH_X2;
-constexpr int kNdMaxD = 6;
-__device__ constexpr int kKap0[kNdTerms] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
-__device__ constexpr int kKap1[kNdTerms] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0};
+template <int TK> constexpr int nd_maxd() { return (TK == 2) ? 7 : 6; }   // per-variable extent bound of the coefficient blocks
+__device__ constexpr int kKap0[kNdTermsHi] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+__device__ constexpr int kKap1[kNdTermsHi] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0, 5, 4, 3, 2, 1, 0, 6, 5, 4, 3, 2, 1, 0};
 
 __device__ __forceinline__ constexpr double ffact(int n, int k) {
     double r = 1.0;
@@ -115,8 +120,11 @@ struct NdTile {
     static constexpr int RW = 16 * ZB + 6;           // reduction row: moments (padded), flag, 5 scalar sums
     static constexpr int oRed = oLam + 2 * NP;       // [4 waves x 4 DPP rows][RW]
     static constexpr int nRed = (TK == 1) ? 16 * RW : 16 * ZB + 16;   // operator path: Jacobi test scratch + the flag slot at [16 ZB]
-    static constexpr int oCoef = oRed + nRed;        // [kNdRows][D][D]
-    static constexpr int oMisc = oCoef + kNdRows * kNdMaxD * kNdMaxD;  // lik params [4], flags [4]
+    static constexpr int kTerms = nd_terms<TK>(), kRows = nd_rows<TK>(), kMaxD = nd_maxd<TK>();
+    static constexpr bool kOperator = (TK != 1);     // operator-table prediction (TK = 0, 2) or Normal closure (TK = 1)
+    static constexpr int FFS = nd_kmax<TK>() + 1;    // falling-factorial table stride: k = 0 .. kmax
+    static constexpr int oCoef = oRed + nRed;        // [kRows][D][D]
+    static constexpr int oMisc = oCoef + kRows * kMaxD * kMaxD;  // lik params [4], flags [4]
     // Tournament index tables, built once per launch: which rows / columns a work item touches in round r depends on
     // (r, item) only, and recomputing it cost ~50 integer instructions per thread per round next to ~30 flops.
     //   KT[r][P * HP + Q] = p1 | p2 << 8 | q1 << 16 | q2 << 24  (u32)
@@ -124,15 +132,15 @@ struct NdTile {
     static constexpr int oIdxK = oMisc + 8;
     static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
     // bilinear-form path: Krylov tiles, the moment array of the rule and its shifted copy, re-centred coefficients
-    static constexpr int NPW = P + kNdMaxD;                  // powers 0 .. 2N-1 + (D-1)
+    static constexpr int NPW = P + kMaxD;                  // powers 0 .. 2N-1 + (D-1)
     static constexpr int MLD = NPW + 1;
     static constexpr int oPK = oIdxK + nIdxK;                // [2][NPW][NP]
     static constexpr int oM = oPK + 2 * NPW * NP;            // [NPW][MLD]
     static constexpr int oM2 = oM + NPW * MLD;               // [NPW][MLD]
-    static constexpr int oQs = oM2 + NPW * MLD;              // [kNdRows][kNdMaxD * kNdMaxD] (operator path)
-    static constexpr int oBin = oQs + ((TK == 0) ? kNdRows * kNdMaxD * kNdMaxD : 0);  // [NPW][NPW] binomial coefficients
-    static constexpr int oBx = oBin + NPW * NPW;             // [kNdMaxD][kNdMaxD] raw-monomial sums, then 8 scalars
-    static constexpr int oLik = oBx + kNdMaxD * kNdMaxD + 8; // [2][4] likelihood factor parameters
+    static constexpr int oQs = oM2 + NPW * MLD;              // [kRows][kMaxD * kMaxD] (operator path)
+    static constexpr int oBin = oQs + (kOperator ? kRows * kMaxD * kMaxD : 0);  // [NPW][NPW] binomial coefficients
+    static constexpr int oBx = oBin + NPW * NPW;             // [kMaxD][kMaxD] spare, then 8 scalars
+    static constexpr int oLik = oBx + kMaxD * kMaxD + 8; // [2][4] likelihood factor parameters
     static constexpr int oPw = oLik + 8;                     // [2][NPW] powers of the centre shift
     // Chebyshev evaluation of lik(X_k) e_0: nodes cos(pi (j + 1/2) / NCH), the cosine table of the coefficient transform,
     // per-matrix coefficients and scratch ([2] x (coefficients NCH, vector ping-pong 2 NP, 8 scalars))
@@ -143,15 +151,15 @@ struct NdTile {
     static constexpr int oChW = oChC + NCH * NCH;            // [2][NCH + nChV + 8]
     static constexpr int nChW = NCH + nChV + 8;
     // operator terms (kappa, alpha, beta) inside the extents of their blocks, packed once per launch, and n!/(n-k)!
-    static constexpr int kMaxTermWords = kNdTerms * kNdMaxD * kNdMaxD;     // 504 u32
+    static constexpr int kMaxTermWords = kTerms * kMaxD * kMaxD;       // 504 / 972 u32
     static constexpr int oTerms = oChW + 2 * nChW;           // [1 + kMaxTermWords] u32 (count first)
     static constexpr int kTermChunk = 8;                     // terms a thread has in flight at once in the contraction
     static constexpr int kTermGroups = (4 * Z <= 256) ? 4 : (3 * Z <= 256) ? 3 : (2 * Z <= 256) ? 2 : 1;   // threads per moment
     static constexpr int kTermPad = kTermGroups * kTermChunk;   // the list is padded to a multiple of this with zero terms
-    static constexpr int oFf = oTerms + ((TK == 0) ? (kMaxTermWords + kTermPad + 2) / 2 : 0);   // [P][5]
+    static constexpr int oFf = oTerms + (kOperator ? (kMaxTermWords + kTermPad + 2) / 2 : 0);   // [P][FFS]
     // gather indices of G, H_0, H_1 as u16 ([3][S][S]), when they fit next to the rest at two workgroups per CU: the
     // per-rule gather then makes no global-memory round trip
-    static constexpr int oGi = oFf + ((TK == 0) ? P * 5 : 0);
+    static constexpr int oGi = oFf + (kOperator ? P * FFS : 0);
     static constexpr int nGi = (3 * S * S + 3) / 4;
     static constexpr bool kGatherLds = (oGi + nGi) * 8 <= 80 * 1024;
     static constexpr int kDoubles = oGi + (kGatherLds ? nGi : 0);
@@ -1009,7 +1017,7 @@ template <int N, int TK>
 __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
-    constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = kNdMaxD * kNdMaxD;
+    constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = L::kMaxD * L::kMaxD;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
     const int tid = threadIdx.x, b = blockIdx.x;
     const bool scaled = a.mode == MFS_MODE_SCALED;
@@ -1020,8 +1028,8 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     const int DD = a.D * a.D;
 
     {
-        const double* src = a.coef + (a.coef_batched ? (size_t)b * kNdRows * DD : 0);
-        for (int e = tid; e < kNdRows * DD; e += 256) Sm[L::oCoef + e] = src[e];
+        const double* src = a.coef + (a.coef_batched ? (size_t)b * L::kRows * DD : 0);
+        for (int e = tid; e < L::kRows * DD; e += 256) Sm[L::oCoef + e] = src[e];
     }
     if constexpr (L::kTables) {
         constexpr int HP = L::HP;
@@ -1045,23 +1053,23 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         if (e < NCH) Sm[L::oChX + e] = cospi(((double)e + 0.5) / NCH);
         else { const int j = (e - NCH) / NCH, i = (e - NCH) % NCH; Sm[L::oChC + j * NCH + i] = cospi((double)i * ((double)j + 0.5) / NCH); }   // [sample j][coefficient i]
     }
-    if constexpr (TK == 0) {   // term list: word = k0 | k1 << 3 | al << 6 | be << 9 | ea << 12 | eb << 15 | (k * 36 + al * 6 + be) << 18
+    if constexpr (L::kOperator) {   // term list: word = k0 | k1 << 3 | al << 6 | be << 9 | ea << 12 | eb << 15 | (k * 36 + al * 6 + be) << 18
         unsigned* tw = reinterpret_cast<unsigned*>(Sm + L::oTerms);
         if (tid == 0) {
             unsigned n = 0;
-            for (int k = 0; k < a.n_terms_used && k < kNdTerms; ++k) {
+            for (int k = 0; k < a.n_terms_used && k < L::kTerms; ++k) {
                 const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
                 for (int al = 0; al < ea; ++al)
                     for (int be = 0; be < eb; ++be)
                         tw[1 + n++] = (unsigned)kKap0[k] | ((unsigned)kKap1[k] << 3) | ((unsigned)al << 6) | ((unsigned)be << 9) |
-                                      ((unsigned)ea << 12) | ((unsigned)eb << 15) | ((unsigned)(k * DD6 + al * kNdMaxD + be) << 18);
+                                      ((unsigned)ea << 12) | ((unsigned)eb << 15) | ((unsigned)(k * DD6 + al * L::kMaxD + be) << 18);
             }
             tw[0] = n;
             // pad to whole chunks with terms that read the always-zero slot of the re-centred table
-            for (int q = 0; q < L::kTermPad; ++q) tw[1 + n + q] = (unsigned)(kNdTerms * DD6) << 18;
+            for (int q = 0; q < L::kTermPad; ++q) tw[1 + n + q] = (unsigned)(L::kTerms * DD6) << 18;
         }
-        if (tid == 0) Sm[L::oQs + kNdTerms * DD6] = 0.0;
-        for (int e = tid; e < P * 5; e += 256) Sm[L::oFf + e] = ffact(e / 5, e % 5) * ((e % 5 <= e / 5) ? 1.0 : 0.0);
+        if (tid == 0) Sm[L::oQs + L::kTerms * DD6] = 0.0;
+        for (int e = tid; e < P * L::FFS; e += 256) Sm[L::oFf + e] = ffact(e / L::FFS, e % L::FFS) * ((e % L::FFS <= e / L::FFS) ? 1.0 : 0.0);
     }
     if constexpr (L::kGatherLds) {
         unsigned short* gi = reinterpret_cast<unsigned short*>(Sm + L::oGi);
@@ -1105,14 +1113,14 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
                 bad = bad || poisoned;
                 double c0 = 0.0, c1 = 0.0, ns0 = 1.0, ns1 = 1.0;
-                if constexpr (TK == 0) {
+                if constexpr (L::kOperator) {
                     ND_STAMP_BEGIN;
                     // ---- the low corner of the rule's moment array about its own centre: all that the new means (and
                     //      scales) need -- a few Krylov steps from e_0
                     const int npow = P + a.D - 1;
                     int nlow = 2;     // extents of the blocks that are summed over the rule: mean rows, variance rows
                     for (int r4 = 0; r4 < (scaled ? 4 : 2); ++r4) {
-                        const int row = (r4 < 2) ? r4 : 12 + r4;
+                        const int row = (r4 < 2) ? r4 : L::kTerms - 2 + r4;
                         nlow = max(nlow, max(a.ext[row] & 0xff, a.ext[row] >> 8));
                     }
                     if (tid < 2 * NP) Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
@@ -1131,7 +1139,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     //      5 k cycles of dependent LDS round trips per step).
                     {
                         const int r4 = tid >> 6, lane = tid & 63;
-                        const int row = (r4 == 0) ? 1 : (r4 == 1) ? 0 : 12 + r4;   // kappa (1,0) is row 1, (0,1) row 0; 14, 15 variances
+                        const int row = (r4 == 0) ? 1 : (r4 == 1) ? 0 : L::kTerms - 2 + r4;   // kappa (1,0) is row 1, (0,1) row 0; the last two rows are the variances
                         double acc = 0.0;
                         if (r4 < 2 || scaled) {
                             const int ea = a.ext[row] & 0xff, eb = a.ext[row] >> 8;
@@ -1204,8 +1212,8 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                             while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
                             const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
                             double v0 = (grp == 0) ? M[n0 * MLD + n1] : 0.0, v1 = 0.0;
-                            const double* f0 = ff + n0 * 5;
-                            const double* f1 = ff + n1 * 5;
+                            const double* f0 = ff + n0 * L::FFS;
+                            const double* f1 = ff + n1 * L::FFS;
                             // A chunk of CH terms at a time, every LDS read of the chunk issued before any arithmetic: the
                             // term words first, then the four operands of each term (the one-term-at-a-time loop was two
                             // dependent LDS round trips per term, 18 k cycles per step).  A term with kappa > n has a zero

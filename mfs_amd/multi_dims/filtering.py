@@ -83,27 +83,33 @@ def _model_struct(tables, factors, B=1):
     if isinstance(factors, sym.LikelihoodSpec):
         factors = [factors]
     dense, D = tables.dense_table()
-    if D > _lib.ND_MAX_EXTENT:
-        raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds MFS_ND_MAX_EXTENT = {_lib.ND_MAX_EXTENT}')
     batched_coef = dense.ndim == 4          # (B, rows, D, D): per-replicate drift / dispersion parameters
     if batched_coef and dense.shape[0] != B:
         raise ValueError(f'transition tables are batched over {dense.shape[0]} replicates, the filter batch is {B}')
     lead = (B,) if batched_coef else ()
-    coef = np.zeros(lead + (_lib.ND_ROWS, D, D))
     if tables.is_gaussian:
+        if D > _lib.ND_MAX_EXTENT:
+            raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds MFS_ND_MAX_EXTENT = {_lib.ND_MAX_EXTENT}')
+        coef = np.zeros(lead + (_lib.ND_ROWS, D, D))
         coef[..., :5, :, :] = dense        # mu_0, mu_1, S_00, S_01, S_11
         kind, last = _lib.ND_TRANS_GAUSSIAN, 5
     else:
-        kind, last = _lib.ND_TRANS_OPERATOR, 0
-        for t, kap in enumerate(tables.kappas):
+        kind, rows_of = _lib.ND_TRANS_OPERATOR, []
+        for kap in tables.kappas:
             kap = tuple(int(v) for v in kap)
             if kap not in _lib.ND_KAPPAS:
-                raise sym.NotDeviceDescribable(f'derivative term {kap} needs |kappa| <= 4, i.e. tme_order <= 2 on the '
+                raise sym.NotDeviceDescribable(f'derivative term {kap} needs |kappa| <= 6, i.e. tme_order <= 3 on the '
                                                'device')
-            row = _lib.ND_KAPPAS.index(kap)
+            rows_of.append(_lib.ND_KAPPAS.index(kap))
+        last = max(rows_of) + 1 if rows_of else 0
+        n_rows = _lib.nd_table_rows(last)                 # 16 rows (|kappa| <= 4) or 29 (TME order 3)
+        max_extent = _lib.ND_MAX_EXTENT_HI if n_rows == _lib.ND_ROWS_MAX else _lib.ND_MAX_EXTENT
+        if D > max_extent:
+            raise sym.NotDeviceDescribable(f'coefficient extent {D} exceeds the device limit {max_extent}')
+        coef = np.zeros(lead + (n_rows, D, D))
+        for t, row in enumerate(rows_of):
             coef[..., row, :, :] = dense[..., t, :, :]
-            last = max(last, row + 1)
-        coef[..., _lib.ND_TERMS:_lib.ND_TERMS + 2, :, :] = tables.var_blocks(D)   # diagonal of tme.mean_and_cov (scaled mode)
+        coef[..., n_rows - 2:, :, :] = tables.var_blocks(D)   # diagonal of tme.mean_and_cov (scaled mode)
     # likelihood factors: [n_factors][MAX_LIK], or [B][n_factors][MAX_LIK] when a factor has per-replicate parameters
     nf = len(factors)
     lik_batched = any(np.asarray(f.params).ndim > 1 for f in factors)

@@ -39,7 +39,7 @@ def _setup(N, tme_order=2):
     return mi, inds, dt, gs, fns, pmf, ogs, ofns, opmf
 
 
-@pytest.mark.parametrize('N,T,tme_order', [(2, 80, 2), (3, 60, 2), (4, 40, 1), (6, 12, 2)])
+@pytest.mark.parametrize('N,T,tme_order', [(2, 80, 2), (3, 60, 2), (4, 40, 1), (6, 12, 2), (3, 40, 3), (4, 20, 3)])
 def test_prey_predator_central_and_raw(N, T, tme_order):
     mi, inds, dt, gs, fns, pmf, ogs, ofns, opmf = _setup(N, tme_order)
     B = 3
@@ -191,3 +191,27 @@ def test_update_by_eigen_decomposition_matches_chebyshev_route(N, T, family, mon
         npt.assert_allclose(eig[2][0], rc[2], rtol=1e-6)
         npt.assert_allclose(eig[1][0], rc[1], rtol=1e-6)
         _assert_moments(eig[0][0], rc[0], mi, rtol=1e-6)
+
+
+def test_tme_order_3_scaled_mode_and_wide_table():
+    """TME order 3 on the operator path: derivative terms up to |kappa| = 6 (27 rows instead of 14) and coefficient blocks of
+    extent 7 -- the long table layout and its kernel instantiation: the central filter against the oracle, and the scaled filter
+    against the central one (reference tests/test_filtering.py:169-242 restated at order 3)."""
+    N, T, B = 3, 30, 2
+    mi, inds, dt, gs, fns, pmf, ogs, ofns, opmf = _setup(N, 3)
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=33)
+    tables = filtering._trace_transition((fns[1], 'multi-index'), 'central')
+    assert int(tables.kappas.sum(axis=1).max()) == 6 and tables.dense_table()[1] == 7
+    scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))
+    scms0 = gs.cms / np.prod(scale0 ** mi, axis=-1)
+    scmss, means_s, scales, nell_s = filtering.moment_filter_nd_scms((fns[2], 'multi-index'), fns[4], pmf, ys, (mi, inds),
+                                                                     scms0, gs.mean, scale0)
+    cmss, means_c, nell_c = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys, (mi, inds), gs.cms,
+                                                           gs.mean)
+    rc = omd.moment_filter_nd_cms((ofns[1], 'multi-index'), ofns[2], opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
+    npt.assert_allclose(nell_c[0], rc[2], rtol=1e-6)
+    npt.assert_allclose(means_c[0], rc[1], rtol=1e-6)
+    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6)
+    npt.assert_allclose(nell_s, nell_c, rtol=1e-6)
+    npt.assert_allclose(means_s, means_c, rtol=1e-6)
+    npt.assert_allclose(scales ** 2, np.stack([cmss[:, :, 5], cmss[:, :, 3]], axis=-1), rtol=1e-6)

@@ -66,9 +66,9 @@ def test_nd_tracing_and_model_struct():
         npt.assert_array_equal(coef[row][:tables.Q[t].coef.shape[0], :tables.Q[t].coef.shape[1]], tables.Q[t].coef)
     with pytest.raises(sym.NotDeviceDescribable):  # likelihood on both components
         filtering._trace_likelihood(lambda y, x: pmf(y, [x[0] + x[1], x[1]]), 2)
-    with pytest.raises(sym.NotDeviceDescribable):  # tme_3 needs |kappa| up to 6
-        r3, c3, *_ = moments.sde_cond_moments_tme(drift, disp, dt, 3)
-        filtering._model_struct(filtering._trace_transition((c3, 'multi-index'), 'central'), lik)
+    with pytest.raises(sym.NotDeviceDescribable):  # tme_4 needs |kappa| up to 8: beyond the device's tables
+        r4, c4, *_ = moments.sde_cond_moments_tme(drift, disp, dt, 4)
+        filtering._model_struct(filtering._trace_transition((c4, 'multi-index'), 'central'), lik)
     with pytest.raises(sym.NotDeviceDescribable):
         moments.sde_cond_moments_tme(lambda x: np.array([x[0] / x[1], x[1]], dtype=object), disp, dt, 2)
 
@@ -183,3 +183,22 @@ def test_d1_family_has_the_same_tables_as_the_1d_factory():
     xs = np.linspace(-1., 1., 5)
     npt.assert_allclose(t.cond_mean(xs), onen[1].tables.cond_mean(xs), rtol=1e-15)
     npt.assert_allclose(t.cond_var(xs), onen[1].tables.cond_var(xs), rtol=1e-15)
+
+
+def test_tme_order_3_uses_the_long_table_layout():
+    """TME order 3 has derivative terms up to |kappa| = 6: 27 operator rows + 2 variance rows, extent up to 7
+    (include/mfs_hip.h: MFS_ND_TABLE_ROWS); order <= 2 keeps the 16-row layout."""
+    from mfs_amd import _lib
+    from mfs_amd.multi_dims import filtering, moments, ss_models
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices
+    mi = generate_graded_lexico_multi_indices(2, 5)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    lik = filtering._trace_likelihood(pmf, 2)
+    for order, rows in ((2, _lib.ND_ROWS), (3, _lib.ND_ROWS_MAX)):
+        fns = moments.sde_cond_moments_tme(drift, disp, dt, order)
+        tables = filtering._trace_transition((fns[1], 'multi-index'), 'central')
+        m, keep = filtering._model_struct(tables, lik)
+        assert keep[0].shape[0] == rows == _lib.nd_table_rows(m.n_terms)
+        assert int(tables.kappas.sum(axis=1).max()) == 2 * order
+        # the variance rows are the last two of either layout
+        np.testing.assert_array_equal(keep[0][rows - 2:], tables.var_blocks(m.extent))

@@ -10,7 +10,7 @@ int run(int argc, char** argv) {
     FILE* f = fopen(argv[1], "rb");
     int hdr[6]; fread(hdr, 4, 6, f);  // T, B, D, n_terms, z, s
     int T = hdr[0], B = hdr[1], D = hdr[2], nt = hdr[3], z = hdr[4], s = hdr[5];
-    std::vector<double> coef(kNdRows * D * D), lik(4), m0(z), mean0(2), ys((size_t)B * T);
+    std::vector<double> coef(nd_rows<TK>() * D * D), lik(4), m0(z), mean0(2), ys((size_t)B * T);
     std::vector<int> inds(3 * s * s);
     fread(coef.data(), 8, coef.size(), f); fread(lik.data(), 8, 4, f); fread(inds.data(), 4, inds.size(), f);
     fread(m0.data(), 8, z, f); fread(mean0.data(), 8, 2, f); fread(ys.data(), 8, ys.size(), f); fclose(f);
@@ -21,7 +21,7 @@ int run(int argc, char** argv) {
     hipMemcpy(dm, m0.data(), z * 8, hipMemcpyHostToDevice); hipMemcpy(dmean, mean0.data(), 16, hipMemcpyHostToDevice);
     hipMemcpy(dys, ys.data(), ys.size() * 8, hipMemcpyHostToDevice); hipMemcpy(di, inds.data(), inds.size() * 4, hipMemcpyHostToDevice);
     FilterNdArgs a{}; a.mode = 1; a.T = T; a.B = B; a.stable = 0; a.n_terms_used = nt; a.D = D; a.n_factors = 1; a.ny = 1;
-    a.fac_kind[0] = 0; a.fac_comp[0] = 0; a.fac_ycol[0] = 0; for (int k = 0; k < kNdRows; ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
+    a.fac_kind[0] = 0; a.fac_comp[0] = 0; a.fac_ycol[0] = 0; for (int k = 0; k < nd_rows<TK>(); ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
     a.out_mom = nullptr; a.out_mean = dmeans; a.out_nell = dnell; a.out_first_nan = nullptr;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     constexpr int lds = NdTile<N, TK>::kDoubles * 8;
