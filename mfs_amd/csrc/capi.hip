@@ -246,7 +246,7 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     alloc((void**)&p->c_scale, (size_t)B * 8);
     alloc((void**)&p->c_nell, (size_t)B * 8);
     alloc((void**)&p->c_first_nan, (size_t)B * 4);
-    if (p->chunk < T && slot >= 3) alloc((void**)&p->c_lam, (size_t)B * p->G * 8);
+    if (p->chunk < T && slot >= 3) alloc((void**)&p->c_lam, (size_t)B * 2 * p->G * 8);
     if (e == hipSuccess) e = hipMemcpy(p->d_coef, model->coef, ncoef * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(p->d_lik, model->lik, nlik * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -309,6 +309,7 @@ static mfs::Filter1dArgs plan_args(const mfs_plan_1d* p, const double* d_m0, int
     a.c_mom = p->c_mom; a.c_mean = p->c_mean; a.c_scale = p->c_scale; a.c_nell = p->c_nell;
     a.c_first_nan = p->c_first_nan;
     a.c_lam = p->c_lam;
+    if (const char* e = getenv("MFS_PREDICT_RULE")) a.recompute_rule = (strcmp(e, "recompute") == 0);   // A/B switch
     a.out_mom = d_out_moments; a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
     a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
     a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;

@@ -408,7 +408,8 @@ __device__ __forceinline__ double likelihood_fast(const int kind, const double* 
 template <int N, int G>
 __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const int grp,
                                                 const double mean, const double scale, double& x_out, double& w_out,
-                                                double& lam_io, const bool recentre = false) {
+                                                double& lam_io, const bool recentre = false, const bool atoms = false,
+                                                const double w_atom = 0.0) {
     static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
     F1_STAMP_BEGIN;
     // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
@@ -533,138 +534,148 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
     });
 
     F1_STAMP(1);
-    // -- Jacobi matrix: a_j = K_jj, b2_j = K_{j+1,j}^2, and the weight normalisers c_j = piv_0 / piv_j
-    double a[N], b2[N];
-    double amin = 1.79e308, amax = -1.79e308, bmax2 = 0.0;
-    static_for<0, N>([&](auto Jc) {
-        constexpr int j = Jc;
-        double aj = sub[j] * ipiv[j];
-        if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
-        a[j] = aj;
-        if constexpr (j < N - 1) {
-            b2[j] = piv[j + 1] * ipiv[j];
-            bmax2 = vmax_f64(bmax2, b2[j]);
-        } else {
-            b2[j] = 0.0;
-        }
-        amin = vmin_f64(amin, aj);
-        amax = vmax_f64(amax, aj);
-    });
-
-    F1_STAMP(2);
     double lam = 0.0, w = 0.0;
-    if (!poisoned) {
-        // -- eigenvalue k by Sturm counts + Laguerre iteration on the characteristic polynomial p_N (Li & Zeng 1994):
-        //    for a polynomial with only real roots the Laguerre step from x towards the right (left) converges
-        //    monotonically and cubically to the nearest root on that side, from ANY distance.  count(x) = number of
-        //    eigenvalues below x tells the lane which root that is: count == k -> step right lands on lambda_k,
-        //    count == k + 1 -> step left does; otherwise bisect the count bracket [lo, hi).
-        // 2 max|b|, rounded up: only has to bound the spectrum (seed + one Newton step, then 1 + 1e-9)
-        double rb = __builtin_amdgcn_rsq(bmax2);
-        rb = fma(rb, fma(-0.5 * bmax2 * rb, rb, 0.5), rb);
-        const double rad = (bmax2 > 0.0) ? 2.000000002 * bmax2 * rb : 0.0;
-        const double width = (amax - amin) + 2.0 * rad;
-        double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
-        const double wscale = fmax(fabs(lo), fabs(hi));
-        const double tol = 1e-15 * wscale;  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
-        const int k = (l < N) ? l : N - 1;
-        // start from this lane's eigenvalue of the previous rule when there is one (the Jacobi matrix moves little
-        // between consecutive quadratures), else spread the lanes over the bracket
-        double x = lo + (hi - lo) * ((double)k + 0.5) * (1.0 / (double)N);
-        if (recentre) {
-            // an approximate start is moved and stretched so that its first two spectral moments are right:
-            // sum lambda = tr J = sum a_j,  sum lambda^2 = tr J^2 = sum a_j^2 + 2 sum b_j^2
-            double tr = 0.0, tr2 = 0.0;
-            static_for<0, N>([&](auto Jc) { tr += a[Jc]; tr2 = fma(a[Jc], a[Jc], tr2 + 2.0 * b2[Jc]); });
-            const double gsel = (l < N) ? lam_io : 0.0;
-            const double g1 = gsum<G>(gsel) * (1.0 / (double)N), g2 = gsum<G>(gsel * gsel) * (1.0 / (double)N);
-            const double m1 = tr * (1.0 / (double)N), v_t = tr2 * (1.0 / (double)N) - m1 * m1, v_g = g2 - g1 * g1;
-            // sqrt(v_t / v_g) to ~1e-7 (it only places a start): v_t rsq(v_t v_g)
-            const double vv = v_t * v_g;
-            double rr = __builtin_amdgcn_rsq(vv);
-            rr = fma(rr, fma(-0.5 * vv * rr, rr, 0.5), rr);
-            const double r = (v_t > 0.0 && v_g > 0.0) ? v_t * rr : 1.0;
-            lam_io = fma(r, lam_io - g1, m1);
-        }
-        if (lam_io > lo && lam_io < hi) x = lam_io;
-        bool conv = false;
-        double prev_step = 0.0;
-        for (int it = 0; it < kMaxEigIters; ++it) {
-#ifdef MFS_1D_STAMPS
-            if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[10] += 1;
-#endif
-            // p, p' and h = p''/2 by the three-term recurrence (h_n = t h_{n-1} - b^2 h_{n-2} - p'_{n-1})
-            double p0 = 1.0, p1 = a[0] - x, d0 = 0.0, d1 = -1.0, e0 = 0.0, e1 = 0.0;
-            // Sturm count = number of sign changes along p_0..p_N.  The sign bits are shifted into one word as the
-            // recurrence runs (one v_alignbit per step; floating-point compares would bounce through SGPR masks next
-            // to the chain) and the changes are counted at the end.  p_0 = 1 > 0 is the zero bit above the first one.
-            unsigned signs = (unsigned)__double2hiint(p1) >> 31;
+    if (atoms) {
+        // The moments are those of an N-atom measure whose atoms the caller holds (the posterior of an update: nodes
+        // x_i, weights w_i l(y, x_i) / p_y), and the N-node Gauss rule of an N-atom measure IS that measure: the
+        // Cholesky above has decided the poisoning exactly as the reference's does, the eigen-decomposition of
+        // quadtures.py:128-133 would only return the atoms again, perturbed by the conditioning of the Hankel matrix
+        // (1e-15 W at N = 7, 1e-9 ... 1e-7 W at N = 15; against 80-digit arithmetic the atoms are the closer of the two).
+        lam = lam_io;
+        w = w_atom;
+    } else {
+        // -- Jacobi matrix: a_j = K_jj, b2_j = K_{j+1,j}^2, and the weight normalisers c_j = piv_0 / piv_j
+        double a[N], b2[N];
+        double amin = 1.79e308, amax = -1.79e308, bmax2 = 0.0;
+        static_for<0, N>([&](auto Jc) {
+            constexpr int j = Jc;
+            double aj = sub[j] * ipiv[j];
+            if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
+            a[j] = aj;
+            if constexpr (j < N - 1) {
+                b2[j] = piv[j + 1] * ipiv[j];
+                bmax2 = vmax_f64(bmax2, b2[j]);
+            } else {
+                b2[j] = 0.0;
+            }
+            amin = vmin_f64(amin, aj);
+            amax = vmax_f64(amax, aj);
+        });
+
+        F1_STAMP(2);
+        if (!poisoned) {
+            // -- eigenvalue k by Sturm counts + Laguerre iteration on the characteristic polynomial p_N (Li & Zeng 1994):
+            //    for a polynomial with only real roots the Laguerre step from x towards the right (left) converges
+            //    monotonically and cubically to the nearest root on that side, from ANY distance.  count(x) = number of
+            //    eigenvalues below x tells the lane which root that is: count == k -> step right lands on lambda_k,
+            //    count == k + 1 -> step left does; otherwise bisect the count bracket [lo, hi).
+            // 2 max|b|, rounded up: only has to bound the spectrum (seed + one Newton step, then 1 + 1e-9)
+            double rb = __builtin_amdgcn_rsq(bmax2);
+            rb = fma(rb, fma(-0.5 * bmax2 * rb, rb, 0.5), rb);
+            const double rad = (bmax2 > 0.0) ? 2.000000002 * bmax2 * rb : 0.0;
+            const double width = (amax - amin) + 2.0 * rad;
+            double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
+            const double wscale = fmax(fabs(lo), fabs(hi));
+            const double tol = 1e-15 * wscale;  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
+            const int k = (l < N) ? l : N - 1;
+            // start from this lane's eigenvalue of the previous rule when there is one (the Jacobi matrix moves little
+            // between consecutive quadratures), else spread the lanes over the bracket
+            double x = lo + (hi - lo) * ((double)k + 0.5) * (1.0 / (double)N);
+            if (recentre) {
+                // an approximate start is moved and stretched so that its first two spectral moments are right:
+                // sum lambda = tr J = sum a_j,  sum lambda^2 = tr J^2 = sum a_j^2 + 2 sum b_j^2
+                double tr = 0.0, tr2 = 0.0;
+                static_for<0, N>([&](auto Jc) { tr += a[Jc]; tr2 = fma(a[Jc], a[Jc], tr2 + 2.0 * b2[Jc]); });
+                const double gsel = (l < N) ? lam_io : 0.0;
+                const double g1 = gsum<G>(gsel) * (1.0 / (double)N), g2 = gsum<G>(gsel * gsel) * (1.0 / (double)N);
+                const double m1 = tr * (1.0 / (double)N), v_t = tr2 * (1.0 / (double)N) - m1 * m1, v_g = g2 - g1 * g1;
+                // sqrt(v_t / v_g) to ~1e-7 (it only places a start): v_t rsq(v_t v_g)
+                const double vv = v_t * v_g;
+                double rr = __builtin_amdgcn_rsq(vv);
+                rr = fma(rr, fma(-0.5 * vv * rr, rr, 0.5), rr);
+                const double r = (v_t > 0.0 && v_g > 0.0) ? v_t * rr : 1.0;
+                lam_io = fma(r, lam_io - g1, m1);
+            }
+            if (lam_io > lo && lam_io < hi) x = lam_io;
+            bool conv = false;
+            double prev_step = 0.0;
+            for (int it = 0; it < kMaxEigIters; ++it) {
+    #ifdef MFS_1D_STAMPS
+                if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[10] += 1;
+    #endif
+                // p, p' and h = p''/2 by the three-term recurrence (h_n = t h_{n-1} - b^2 h_{n-2} - p'_{n-1})
+                double p0 = 1.0, p1 = a[0] - x, d0 = 0.0, d1 = -1.0, e0 = 0.0, e1 = 0.0;
+                // Sturm count = number of sign changes along p_0..p_N.  The sign bits are shifted into one word as the
+                // recurrence runs (one v_alignbit per step; floating-point compares would bounce through SGPR masks next
+                // to the chain) and the changes are counted at the end.  p_0 = 1 > 0 is the zero bit above the first one.
+                unsigned signs = (unsigned)__double2hiint(p1) >> 31;
+                static_for<1, N>([&](auto Jc) {
+                    constexpr int j = Jc;
+                    const double t = a[j] - x;
+                    const double pn = fma(t, p1, -b2[j - 1] * p0);
+                    const double dn = fma(t, d1, fma(-b2[j - 1], d0, -p1));
+                    const double en = fma(t, e1, fma(-b2[j - 1], e0, -d1));
+                    signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(pn), 31);
+                    p0 = p1; p1 = pn; d0 = d1; d1 = dn; e0 = e1; e1 = en;
+                });
+                const int cnt = __popc(signs ^ (signs >> 1));
+                {   // straight-line and predicated (bitwise, not short-circuit, logic: no divergent branches in the loop);
+                    // a converged lane is frozen by the selects at the end
+                    const bool below = cnt <= k;
+                    const double lo_n = below ? x : lo, hi_n = below ? hi : x;
+                    const double mid = 0.5 * (lo_n + hi_n);
+                    // S = sqrt((N-1) ((N-1) p'^2 - N p p'')) >= 0 for real-rooted p (clamped against rounding)
+                    // (the step only has to be accurate enough to converge: seeds + one Newton step instead of
+                    //  full-precision sqrt / divide; the accuracy of the root comes from the recurrence evaluation)
+                    const double disc = fmax((double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)(2 * N) * p1 * e1), 0.0);
+                    double rs = __builtin_amdgcn_rsq(disc);
+                    rs = fma(rs, fma(-0.5 * disc * rs, rs, 0.5), rs);
+                    const double S = copysign(disc > 0.0 ? disc * rs : 0.0, p1);
+                    const bool right = (cnt == k), left = (cnt == k + 1);
+                    const double den = right ? (d1 - S) : (d1 + S);
+                    double rd = __builtin_amdgcn_rcp(den);
+                    rd = fma(fma(-den, rd, 1.0), rd, rd);
+                    double xn = x - (double)N * p1 * rd;
+                    const bool ok = (right & (xn >= x) & (xn < hi_n)) | (left & (xn <= x) & (xn > lo_n));  // false for NaN
+                    xn = ok ? xn : mid;
+                    // Laguerre converges cubically near its root: e_next ~ e^3 / gap^2 with gap >~ W / N, so a step below
+                    // 1e-6 W lands within ~N^2 1e-18 W of the root and the confirming evaluation can be skipped -- but only
+                    // with evidence of that regime: a small step also occurs right after leaving the neighbourhood of a
+                    // DIFFERENT root (steps then grow by ~N/(N-2) per iteration).  Hence: small AND at least 100x smaller
+                    // than the previous Laguerre step of this lane ...
+                    const double step = fabs(xn - x);
+                    // ... or with the bound that needs no history: p'/p = sum_i 1/(x - lambda_i), so when the Newton step
+                    // -p/p' points the way we travel, the roots ahead dominate that sum and the nearest of them lies within
+                    // N |p/p'| of x.  If that is below 3e-7 W, the Laguerre step lands within ~(3e-7)^3 (N/W)^2 W of it.
+                    // (This is what accepts, after ONE evaluation, the predict-half rule started from the reweighted
+                    //  update-half rule -- see the kernel.)
+                    const double nwt = -p1 * d1;   // sign of the Newton step -p/p'
+                    const bool ahead = right ? (nwt > 0.0) : (nwt < 0.0);
+                    const bool near = ok & ahead & ((double)N * fabs(p1) <= (3e-7 * wscale) * fabs(d1));
+                    const bool conv_n = (ok & (step <= tol)) | (ok & (step <= kLagStop * wscale) & (step <= 1e-2 * prev_step)) |
+                                        near | (hi_n - lo_n <= tol) | ((p1 == 0.0) & (right | left));
+                    lo = conv ? lo : lo_n;
+                    hi = conv ? hi : hi_n;
+                    prev_step = conv ? prev_step : (ok ? step : 0.0);
+                    x = conv ? x : xn;
+                    conv = conv | conv_n;
+                }
+                if (gall<G>(conv, grp)) break;
+            }
+            lam = x;
+            lam_io = x;
+            F1_STAMP(3);
+            // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2, c_j = piv_0 / piv_j  (quadtures.py:133, V[0, :]**2)
+            double p0 = 1.0, p1 = a[0] - lam, acc = ipiv[0], acc2 = 0.0;
             static_for<1, N>([&](auto Jc) {
                 constexpr int j = Jc;
-                const double t = a[j] - x;
-                const double pn = fma(t, p1, -b2[j - 1] * p0);
-                const double dn = fma(t, d1, fma(-b2[j - 1], d0, -p1));
-                const double en = fma(t, e1, fma(-b2[j - 1], e0, -d1));
-                signs = __builtin_amdgcn_alignbit(signs, (unsigned)__double2hiint(pn), 31);
-                p0 = p1; p1 = pn; d0 = d1; d1 = dn; e0 = e1; e1 = en;
+                if constexpr (j % 2 == 1) acc = fma(ipiv[j] * p1, p1, acc); else acc2 = fma(ipiv[j] * p1, p1, acc2);
+                const double pn = fma(a[j] - lam, p1, -b2[j - 1] * p0);
+                p0 = p1; p1 = pn;
             });
-            const int cnt = __popc(signs ^ (signs >> 1));
-            {   // straight-line and predicated (bitwise, not short-circuit, logic: no divergent branches in the loop);
-                // a converged lane is frozen by the selects at the end
-                const bool below = cnt <= k;
-                const double lo_n = below ? x : lo, hi_n = below ? hi : x;
-                const double mid = 0.5 * (lo_n + hi_n);
-                // S = sqrt((N-1) ((N-1) p'^2 - N p p'')) >= 0 for real-rooted p (clamped against rounding)
-                // (the step only has to be accurate enough to converge: seeds + one Newton step instead of
-                //  full-precision sqrt / divide; the accuracy of the root comes from the recurrence evaluation)
-                const double disc = fmax((double)(N - 1) * fma((double)(N - 1) * d1, d1, -(double)(2 * N) * p1 * e1), 0.0);
-                double rs = __builtin_amdgcn_rsq(disc);
-                rs = fma(rs, fma(-0.5 * disc * rs, rs, 0.5), rs);
-                const double S = copysign(disc > 0.0 ? disc * rs : 0.0, p1);
-                const bool right = (cnt == k), left = (cnt == k + 1);
-                const double den = right ? (d1 - S) : (d1 + S);
-                double rd = __builtin_amdgcn_rcp(den);
-                rd = fma(fma(-den, rd, 1.0), rd, rd);
-                double xn = x - (double)N * p1 * rd;
-                const bool ok = (right & (xn >= x) & (xn < hi_n)) | (left & (xn <= x) & (xn > lo_n));  // false for NaN
-                xn = ok ? xn : mid;
-                // Laguerre converges cubically near its root: e_next ~ e^3 / gap^2 with gap >~ W / N, so a step below
-                // 1e-6 W lands within ~N^2 1e-18 W of the root and the confirming evaluation can be skipped -- but only
-                // with evidence of that regime: a small step also occurs right after leaving the neighbourhood of a
-                // DIFFERENT root (steps then grow by ~N/(N-2) per iteration).  Hence: small AND at least 100x smaller
-                // than the previous Laguerre step of this lane ...
-                const double step = fabs(xn - x);
-                // ... or with the bound that needs no history: p'/p = sum_i 1/(x - lambda_i), so when the Newton step
-                // -p/p' points the way we travel, the roots ahead dominate that sum and the nearest of them lies within
-                // N |p/p'| of x.  If that is below 3e-7 W, the Laguerre step lands within ~(3e-7)^3 (N/W)^2 W of it.
-                // (This is what accepts, after ONE evaluation, the predict-half rule started from the reweighted
-                //  update-half rule -- see the kernel.)
-                const double nwt = -p1 * d1;   // sign of the Newton step -p/p'
-                const bool ahead = right ? (nwt > 0.0) : (nwt < 0.0);
-                const bool near = ok & ahead & ((double)N * fabs(p1) <= (3e-7 * wscale) * fabs(d1));
-                const bool conv_n = (ok & (step <= tol)) | (ok & (step <= kLagStop * wscale) & (step <= 1e-2 * prev_step)) |
-                                    near | (hi_n - lo_n <= tol) | ((p1 == 0.0) & (right | left));
-                lo = conv ? lo : lo_n;
-                hi = conv ? hi : hi_n;
-                prev_step = conv ? prev_step : (ok ? step : 0.0);
-                x = conv ? x : xn;
-                conv = conv | conv_n;
-            }
-            if (gall<G>(conv, grp)) break;
+            w = rcp_sat(piv[0] * (acc + acc2));   // the sum overflows for the outermost nodes of large rules: weight 0, not NaN
+            F1_STAMP(4);
         }
-        lam = x;
-        lam_io = x;
-        F1_STAMP(3);
-        // -- squared first eigenvector component: 1 / sum_j c_j p_j(lam)^2, c_j = piv_0 / piv_j  (quadtures.py:133, V[0, :]**2)
-        double p0 = 1.0, p1 = a[0] - lam, acc = ipiv[0], acc2 = 0.0;
-        static_for<1, N>([&](auto Jc) {
-            constexpr int j = Jc;
-            if constexpr (j % 2 == 1) acc = fma(ipiv[j] * p1, p1, acc); else acc2 = fma(ipiv[j] * p1, p1, acc2);
-            const double pn = fma(a[j] - lam, p1, -b2[j - 1] * p0);
-            p0 = p1; p1 = pn;
-        });
-        w = rcp_sat(piv[0] * (acc + acc2));   // the sum overflows for the outermost nodes of large rules: weight 0, not NaN
-        F1_STAMP(4);
     }
     const double qnan = __builtin_nan("");
     x_out = poisoned ? qnan : ((l < N) ? fma(scale, lam, mean) : mean);
@@ -734,19 +745,25 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
     bool dead = (first_nan >= 0);
     const double qnan = __builtin_nan("");
     const bool node = (l < N);
-    // Warm starts of the eigenvalue iterations.  The posterior moments of the update half are the moments of the
-    // N-atom measure {x_i, w_i l(y, x_i) / p_y}, and the Gauss rule of an N-atom measure is that measure: in exact
-    // arithmetic the predict-half rule of the next step has the SAME nodes.  The reference recomputes it from the
-    // moments (Cholesky + eigensolve, quadtures.py:122-133), and so does this kernel -- its pivots decide the NaN
-    // poisoning and its rounding is part of the reference's numbers -- but the eigenvalue iteration starts from
-    // (x_i - mean) / scale, which is right up to that rounding (1e-15 W at N = 7, ~1e-9 W at N = 15) and is
-    // normally accepted after one evaluation.  The update-half rule (the predicted law is a mixture of N continuous
-    // kernels, not N atoms) starts from the predict-half eigenvalues, moved and stretched to the trace and the squared
-    // Frobenius norm of the new Jacobi matrix.  Measured on config 2: 1.2 + 3.0 Laguerre evaluations per step instead
-    // of 4 + 4.  A start only steers the iteration, never the result; the pending start is part of the carry so that a
-    // chunked run is bit-identical.
-    double gA = qnan;
-    if (a.t_begin != 0 && a.c_lam) gA = a.c_lam[(size_t)b * G + l];
+    // The two rules of a step.  The posterior moments of the update half are the moments of the N-atom measure
+    // {x_i, w_i l(y, x_i) / p_y}, and the N-node Gauss rule of an N-atom measure is that measure: in exact arithmetic the
+    // predict-half rule of the next step IS the set of atoms this lane group already holds.  The reference reconstructs it
+    // from the moments (Cholesky + eigensolve, quadtures.py:122-133); the kernel runs the Cholesky -- its pivots decide
+    // the NaN poisoning exactly as upstream -- and takes nodes and weights from the atoms (MFS_PREDICT_RULE=recompute: the
+    // reconstruction, started from the atoms and normally accepted after one Laguerre evaluation; the two differ by the
+    // conditioning of the Hankel matrix, 1e-15 W at N = 7, 1e-9 ... 1e-7 W at N = 15, and against 80-digit arithmetic
+    // they are equally close: tests/test_gpu_envelope.py).  The update-half rule (the predicted law is a mixture of N
+    // continuous kernels, not N atoms) is computed in full; its eigenvalue iteration starts from the predict-half nodes,
+    // moved and stretched to the trace and the squared Frobenius norm of the new Jacobi matrix (3.0 Laguerre evaluations
+    // instead of 4 from the previous update rule's own eigenvalues).  A start only steers the iteration, never the
+    // result; the atoms are part of the carry, so a chunked run is bit-identical.
+    double gA = qnan, gW = 0.0;        // the posterior atoms of the last update, in rule units: nodes and weights
+    bool have_atoms = false;
+    if (a.t_begin != 0 && a.c_lam) {
+        gA = a.c_lam[((size_t)b * 2 + 0) * G + l];
+        gW = a.c_lam[((size_t)b * 2 + 1) * G + l];
+        have_atoms = true;
+    }
     double ywin = 0.0;                  // window of measurements (16 steps, or G when G < 16), one per lane
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
@@ -771,7 +788,10 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
 #ifdef MFS_1D_STAMPS
                 const unsigned long long it_before = g_1d_stamps[10];
 #endif
-                quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w, lam_io, half == 1);
+                // predict half: the rule of the posterior moments is the posterior's own atoms (see quadrature_fast); the
+                // reference's recomputation stays available as an A/B switch
+                const bool atoms = (half == 0) & have_atoms & (a.recompute_rule == 0);
+                quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w, lam_io, half == 1, atoms, gW);
                 if (half == 0) gB = lam_io;
 #ifdef MFS_1D_STAMPS
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[11 + half] += g_1d_stamps[10] - it_before;
@@ -845,6 +865,8 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
                     {   // the spare lanes shadow the last eigenvalue (the DPP read must run with the node lanes active)
                         const double last = bcast<G, N - 1>(dx);
                         gA = node ? dx : last;
+                        gW = wl * ipy;                 // (0 in the spare lanes)
+                        have_atoms = true;
                     }
                     double* row = TAB + l * TLD;
                     {   // wl dx^n in four interleaved chains (a dependent multiply costs several issue slots)
@@ -909,7 +931,7 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
         }
     } else {
         for (int n = l; n < M2; n += G) a.c_mom[(size_t)b * M2 + n] = mom[n];
-        if (a.c_lam) a.c_lam[(size_t)b * G + l] = gA;
+        if (a.c_lam) { a.c_lam[((size_t)b * 2 + 0) * G + l] = gA; a.c_lam[((size_t)b * 2 + 1) * G + l] = gW; }
         if (l == 0) {
             a.c_mean[b] = mean; a.c_scale[b] = scale; a.c_nell[b] = nell; a.c_first_nan[b] = first_nan;
         }

@@ -45,7 +45,9 @@ struct Filter1dArgs {
     double* c_scale;
     double* c_nell;
     int32_t* c_first_nan;
-    double* c_lam;  // [B][G] pending eigenvalue warm start of the next predict half (fast path, chunked runs only)
+    double* c_lam;  // [B][2][G] nodes (in rule units) and weights of the posterior atoms, i.e. the next predict-half rule (fast
+                    // path, chunked runs only)
+    int recompute_rule;   // 1: the predict-half rule is recomputed from the posterior moments (MFS_PREDICT_RULE=recompute)
     // outputs (any may be null except out_nell)
     double* out_mom;
     double* out_mean;

@@ -189,3 +189,49 @@ def test_three_way_envelope_at_benchmark_size(golden_dir):
     err = np.abs(means[both][:, st] - g['central_means'][both]) / np.maximum(np.abs(g['central_means'][both]), sd)
     print('common survivors', int(both.sum()), 'mean error vs numpy: max %.1e p99 %.1e' % (err.max(), np.quantile(err, .99)))
     assert np.quantile(err, .99) <= 1e-6
+
+
+def test_predict_rule_from_posterior_atoms_vs_recomputed(golden_dir, monkeypatch):
+    """The posterior of an update is an N-atom measure, and the N-node Gauss rule of an N-atom measure is that measure: the
+    kernel takes the next predict-half rule from the atoms it already holds (the Cholesky of the posterior moments still
+    decides the poisoning) instead of reconstructing it by the eigen-decomposition of quadtures.py:128-133.
+    MFS_PREDICT_RULE=recompute restores the reconstruction.  Checked here: (i) where the reconstruction is well
+    conditioned (N = 7, 10) the two routes give the same filter to 1e-9; (ii) at N = 15, where they differ by the
+    conditioning of the Hankel matrix, BOTH stay within the same bounds against 80-digit arithmetic (measured: NLL 3.2e-11 /
+    3.2e-11, mean 1.2e-9 / 2.2e-9, variance 7.8e-9 / 1.8e-8, moments 1.0e-7 / 6.5e-8 for atoms / recomputed, with 17 / 15 of the 24
+    replicates surviving 300 steps; in exact arithmetic all do)."""
+    # (i)
+    for N, T in ((7, 100), (10, 100)):
+        dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+        f = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+        ys = synth.benes_bernoulli_batch(16, T, dt, seed=5 + N)[0]
+        a = filtering.moment_filter_cms(f[1], f[3], pmf, ic.cms, ic.mean, ys)
+        monkeypatch.setenv('MFS_PREDICT_RULE', 'recompute')
+        r = filtering.moment_filter_cms(f[1], f[3], pmf, ic.cms, ic.mean, ys)
+        monkeypatch.delenv('MFS_PREDICT_RULE')
+        assert np.all(np.isfinite(a[2])) and np.all(np.isfinite(r[2]))
+        npt.assert_allclose(a[2], r[2], rtol=1e-9)
+        npt.assert_allclose(a[1], r[1], rtol=1e-9, atol=1e-12)
+        err = parity.rel_err(a[0], r[0], parity.moment_floor(r[0]))
+        assert np.nanmax(err) <= (1e-9 if N == 7 else 1e-7), np.nanmax(err)
+    # (ii)
+    e = _load(golden_dir, 'filter_cfg2_exact.npz')
+    N, ic, f, pmf, ys_full, oic, tab = _setup()
+    T, B = int(e['T']), int(e['B'])
+    ys, steps = ys_full[:B, :T], e['moment_steps']
+    worst = {}
+    for route in ('atoms', 'recompute'):
+        if route == 'recompute':
+            monkeypatch.setenv('MFS_PREDICT_RULE', 'recompute')
+        m, means, second, nell, fn = _device('central', ic, f, pmf, ys)
+        if route == 'recompute':
+            monkeypatch.delenv('MFS_PREDICT_RULE')
+        survivors = int((fn < 0).sum())                     # (in exact arithmetic all 24 survive; in fp64 about two thirds)
+        assert survivors >= B // 2
+        err = _errors(m[:, steps], means, second, nell, e, 'central')
+        worst[route] = {k: float(v.max()) for k, v in err.items()}
+        worst[route]['survivors'] = survivors
+        assert worst[route]['nll'] <= 1e-9 and worst[route]['mean'] <= 1e-7 and worst[route]['second'] <= 1e-6
+        assert worst[route]['moments'] <= 1e-6
+    print(worst)
+    assert worst['atoms']['survivors'] >= worst['recompute']['survivors'] - 1     # fewer fp64 casualties, if anything
