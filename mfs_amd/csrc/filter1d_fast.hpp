@@ -133,7 +133,12 @@ __device__ __forceinline__ void fnma_bcast_range(double* acc, const double u, co
     if constexpr (J0 < J1) {
         constexpr int n8 = (J1 - J0) / 8;
         static_for<0, n8>([&](auto Pc) { fnma_bcast8<J0 - OFF + 8 * Pc>(acc + J0 + 8 * Pc, u, v); });
-        static_for<J0 + 8 * n8, J1>([&](auto Jc) { fnma_bcast<16, Jc - OFF>(acc[Jc], u, v); });
+        constexpr int j4 = J0 + 8 * n8, rem = J1 - j4;            // the remainder in blocks of 4 / 2 / 1: one hazard nop per block
+        if constexpr (rem >= 4) fnma_bcast4<j4 - OFF, j4 - OFF + 1, j4 - OFF + 2, j4 - OFF + 3>(acc[j4], acc[j4 + 1], acc[j4 + 2], acc[j4 + 3], u, v);
+        constexpr int j2 = j4 + ((rem >= 4) ? 4 : 0), rem2 = J1 - j2;
+        if constexpr (rem2 >= 2) fnma_bcast2<j2 - OFF, j2 - OFF + 1>(acc[j2], acc[j2 + 1], u, v);
+        constexpr int j1 = j2 + ((rem2 >= 2) ? 2 : 0);
+        if constexpr (j1 < J1) fnma_bcast<16, j1 - OFF>(acc[j1], u, v);
     }
 }
 

@@ -255,6 +255,45 @@ __device__ __forceinline__ double likelihood_nd(const int kind, const double* __
     return likelihood(kind, lp, y, x);
 }
 
+// acc[j] -= u * (v of lane j - OFF of this lane's DPP row) for j = J0 .. J1 - 1 as blocks of 8 / 4 / 2 / 1 fused DPP
+// multiply-adds.  Only the FIRST block of a range carries the hazard nop (two wait states between the VALU write of the
+// DPP source and its first DPP read); the later blocks read the same, by then long-written source.  The blocks have
+// disjoint outputs, so a token operand chains them: without it the scheduler may hoist a nop-less block in front of
+// the first one.
+template <int CNT, int J0, bool NOP>
+__device__ __forceinline__ void fnma_chain_block(double* a, const double u, const double v, int& tok) {
+    if constexpr (CNT == 8) {
+        if constexpr (NOP) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %9, -%10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %9, -%10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %9, -%10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %9, -%10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %9, -%10 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %9, -%10 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %9, -%10 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %9, -%10 row_newbcast:%18 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3), "n"(J0 + 4), "n"(J0 + 5), "n"(J0 + 6), "n"(J0 + 7));
+        else asm("v_fmac_f64_dpp %0, %9, -%10 row_newbcast:%11 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %9, -%10 row_newbcast:%12 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %9, -%10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %9, -%10 row_newbcast:%14 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %4, %9, -%10 row_newbcast:%15 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %9, -%10 row_newbcast:%16 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %6, %9, -%10 row_newbcast:%17 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %9, -%10 row_newbcast:%18 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3), "n"(J0 + 4), "n"(J0 + 5), "n"(J0 + 6), "n"(J0 + 7));
+    }
+    if constexpr (CNT == 4) {
+        if constexpr (NOP) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %5, -%6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %5, -%6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %5, -%6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %5, -%6 row_newbcast:%10 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3));
+        else asm("v_fmac_f64_dpp %0, %5, -%6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %5, -%6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %2, %5, -%6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %5, -%6 row_newbcast:%10 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0), "n"(J0 + 1), "n"(J0 + 2), "n"(J0 + 3));
+    }
+    if constexpr (CNT == 2) {
+        if constexpr (NOP) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %3, -%4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %3, -%4 row_newbcast:%6 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(a[1]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0), "n"(J0 + 1));
+        else asm("v_fmac_f64_dpp %0, %3, -%4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %3, -%4 row_newbcast:%6 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(a[1]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0), "n"(J0 + 1));
+    }
+    if constexpr (CNT == 1) {
+        if constexpr (NOP) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %2, -%3 row_newbcast:%4 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0));
+        else asm("v_fmac_f64_dpp %0, %2, -%3 row_newbcast:%4 row_mask:0xf bank_mask:0xf" : "+v"(a[0]), "+v"(tok) : "v"(v), "v"(u), "n"(J0 + 0));
+    }
+}
+template <int J0, int J1, int OFF>
+__device__ __forceinline__ void fnma_chain_range(double* acc, const double u, const double v) {
+    if constexpr (J0 < J1) {
+        int tok = 0;
+        constexpr int n8 = (J1 - J0) / 8;
+        static_for<0, n8>([&](auto Pc) { fnma_chain_block<8, J0 - OFF + 8 * Pc, Pc == 0>(acc + J0 + 8 * Pc, u, v, tok); });
+        constexpr int j4 = J0 + 8 * n8, rem = J1 - j4;
+        if constexpr (rem >= 4) fnma_chain_block<4, j4 - OFF, j4 == J0>(acc + j4, u, v, tok);
+        constexpr int j2 = j4 + ((rem >= 4) ? 4 : 0), rem2 = J1 - j2;
+        if constexpr (rem2 >= 2) fnma_chain_block<2, j2 - OFF, j2 == J0>(acc + j2, u, v, tok);
+        constexpr int j1 = j2 + ((rem2 >= 2) ? 2 : 0);
+        if constexpr (j1 < J1) fnma_chain_block<1, j1 - OFF, j1 == J0>(acc + j1, u, v, tok);
+    }
+}
+
 // pair p of round r in the round-robin tournament on NP players
 template <int NP>
 __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p, int& q) {
@@ -345,13 +384,13 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
                     if constexpr (j < S0) { half_dup(ev, lo, up); D0[j] = lo; }
                     if constexpr (S > 16) { half_dup(od, lo, up); D1[j] = lo; }
                     if constexpr (j + 1 < loE) {
-                        fnma_bcast_range<j + 1, loE, 0>(Lr, Lr[j], D0[j]);
-                        if constexpr (!kMerged) fnma_bcast_range<j + 1, loE, 0>(xc, xc[j], D0[j]);
+                        fnma_chain_range<j + 1, loE, 0>(Lr, Lr[j], D0[j]);
+                        if constexpr (!kMerged) fnma_chain_range<j + 1, loE, 0>(xc, xc[j], D0[j]);
                     }
                     if constexpr (S > 16) {
                         constexpr int hi0 = (j + 1 > 16) ? j + 1 : 16;
-                        fnma_bcast_range<hi0, S, 16>(Lr, Lr[j], D1[j]);
-                        if constexpr (!kMerged) fnma_bcast_range<hi0, S, 16>(xc, xc[j], D1[j]);
+                        fnma_chain_range<hi0, S, 16>(Lr, Lr[j], D1[j]);
+                        if constexpr (!kMerged) fnma_chain_range<hi0, S, 16>(xc, xc[j], D1[j]);
                     }
                 }
             });
@@ -368,10 +407,10 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
             static_for<0, S>([&](auto Ic) {
                 constexpr int i = Ic;
                 yr[i] = yr[i] * rinv_lds[i];
-                if constexpr (i + 1 < loE) fnma_bcast_range<i + 1, loE, 0>(yr, yr[i], D0[i]);
+                if constexpr (i + 1 < loE) fnma_chain_range<i + 1, loE, 0>(yr, yr[i], D0[i]);
                 if constexpr (S > 16 && i + 1 < S) {
                     constexpr int hi0 = (i + 1 > 16) ? i + 1 : 16;
-                    fnma_bcast_range<hi0, S, 16>(yr, yr[i], D1[i]);
+                    fnma_chain_range<hi0, S, 16>(yr, yr[i], D1[i]);
                 }
             });
             wave_sync();
@@ -753,14 +792,23 @@ __device__ void weights_nd(double* __restrict__ Sm) {
 // of another, then entry j is `row_newbcast:j mod 16` of the one or the other -- S fused instructions and one lane swap.
 // (Measured per product at S = 21, cycles: v_readlane pairs as the compiler schedules them, through one scalar pair, 660;
 // the vector re-read from LDS by every lane 600; readlanes batched into distinct scalar registers 445; this form 250.)
-template <int J0, int J1, int J2>
+template <int J0, int J1, int J2, bool NOP>
 __device__ __forceinline__ void fma_bcast3(double& a0, double& a1, double& a2, const double s0, const double s1,
                                            const double s2, const double k0, const double k1, const double k2) {
-    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
-        : "+v"(a0), "+v"(a1), "+v"(a2)
-        : "v"(s0), "v"(s1), "v"(s2), "v"(k0), "v"(k1), "v"(k2), "n"(J0), "n"(J1), "n"(J2));
+    // (the blocks of one product are chained through the three accumulators, so only the first needs the hazard nop
+    //  after the lane swap that wrote the DPP sources)
+    if constexpr (NOP)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %3, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+            : "+v"(a0), "+v"(a1), "+v"(a2)
+            : "v"(s0), "v"(s1), "v"(s2), "v"(k0), "v"(k1), "v"(k2), "n"(J0), "n"(J1), "n"(J2));
+    else
+        asm("v_fmac_f64_dpp %0, %3, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %1, %4, %7 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+            "v_fmac_f64_dpp %2, %5, %8 row_newbcast:%11 row_mask:0xf bank_mask:0xf"
+            : "+v"(a0), "+v"(a1), "+v"(a2)
+            : "v"(s0), "v"(s1), "v"(s2), "v"(k0), "v"(k1), "v"(k2), "n"(J0), "n"(J1), "n"(J2));
 }
 template <int J0>
 __device__ __forceinline__ void fma_bcast1(double& a0, const double s0, const double k0) {
@@ -775,7 +823,7 @@ __device__ __forceinline__ double dpp_matvec(const double (&kr)[S], const double
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
     static_for<0, S / 3>([&](auto Bc) {
         constexpr int j = 3 * Bc;
-        fma_bcast3<j % 16, (j + 1) % 16, (j + 2) % 16>(a0, a1, a2, (j < 16) ? d0 : d1, (j + 1 < 16) ? d0 : d1,
+        fma_bcast3<j % 16, (j + 1) % 16, (j + 2) % 16, j == 0>(a0, a1, a2, (j < 16) ? d0 : d1, (j + 1 < 16) ? d0 : d1,
                                                        (j + 2 < 16) ? d0 : d1, kr[j], kr[j + 1], kr[j + 2]);
     });
     if constexpr (S % 3 >= 1) fma_bcast1<(S - S % 3) % 16>(a0, (S - S % 3 < 16) ? d0 : d1, kr[S - S % 3]);
