@@ -304,7 +304,7 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
 // Front end of a rule: gather, Cholesky (or LDL^T completion), both triangular solves, symmetrisation.  Leaves the
 // symmetric K_0, K_1 in their LDS tiles; returns the block-uniform poison flag (a pivot that is not > 0).
 template <int N, int TK>
-__device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
+__device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -357,7 +357,8 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
             const int xm = xc_lane / S, xj = xc_lane - xm * S;
             const bool is_row = tid < S;
             double Lr[S], xc[kMerged ? 1 : S];
-            double* rinv_lds = Sm + L::oRed;          // 1 / L_jj, parked in LDS between the two solves (registers are short)
+            double rinvs[S];                          // 1 / L_jj: every lane computes the same numbers, so they simply stay in registers
+                                                      // (parking them in LDS cost a branch, a scalar load and a store per column)
             double D0[S0], D1[(S > 16) ? S : 1];      // column k of L: DPP row 0 / DPP row 1 of it in all four rows
             static_for<0, S>([&](auto Jc) {
                 const double gv = A[li * LD + Jc], hv = K[xm * NP * LD + Jc * LD + xj];
@@ -375,7 +376,7 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
                 const double pj = bcast<64, j>(s);
                 bad |= !(pj > 0.0);
                 const double rinv = rsq_nr(pj);
-                if (tid == 0) rinv_lds[j] = rinv;
+                rinvs[j] = rinv;
                 Lr[j] = s * rinv;       // row j itself gets sqrt(piv) = piv * rinv
                 if constexpr (!kMerged) xc[j] = xc[j] * rinv;
                 if constexpr (j + 1 < S) {   // column j is final: spread its two DPP rows over the wave
@@ -406,7 +407,7 @@ __device__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ in
             static_for<0, S>([&](auto Jc) { yr[Jc] = K[hm * NP * LD + hj * LD + Jc]; });
             static_for<0, S>([&](auto Ic) {
                 constexpr int i = Ic;
-                yr[i] = yr[i] * rinv_lds[i];
+                yr[i] = yr[i] * rinvs[i];
                 if constexpr (i + 1 < loE) fnma_chain_range<i + 1, loE, 0>(yr, yr[i], D0[i]);
                 if constexpr (S > 16 && i + 1 < S) {
                     constexpr int hi0 = (i + 1 > 16) ? i + 1 : 16;
@@ -1154,12 +1155,17 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     for (int t = 0; t < a.T; ++t) {
         if (!dead) {
             bool bad = false;
+            // The two half-steps share ONE call site of the front end (inlined there: as a called function it saved and
+            // restored two dozen callee-saved registers through scratch on every call, and twice inlined it doubles the
+            // largest piece of straight-line code in the kernel).
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
+            const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
+            bad = bad || poisoned;
             // =========================================================================================================
             // prediction (filtering.py:262-266 / :330-331 / :183-190)
             // =========================================================================================================
-            {
-                const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
-                bad = bad || poisoned;
+            if (half == 0) {
                 double c0 = 0.0, c1 = 0.0, ns0 = 1.0, ns1 = 1.0;
                 if constexpr (L::kOperator) {
                     ND_STAMP_BEGIN;
@@ -1421,9 +1427,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             // =========================================================================================================
             // update (filtering.py:268-275 / :333-339 / :192-202): bilinear form with h_k = lik_k(X_k) e_0
             // =========================================================================================================
-            {
-                const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
-                bad = bad || poisoned;
+            else {
                 // h_k = lik_k(X_k) e_0 and K_k h_k: Chebyshev evaluation (no eigen-decomposition), checked; they give p_y and the
                 // posterior mean, and the powers of the matrices shifted THERE give the posterior central moments directly.
                 // Cyclic Jacobi + spectral evaluation (and a binomial shift of the moment array) only if the coefficients of
@@ -1540,6 +1544,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
 #endif
             }
+            }   // half
             bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1) || !finite(scale0) || !finite(scale1);
             if (bad) { dead = true; if (tid == 0) Sm[L::oMisc + 5] = __hiloint2double(0, t); }
         } else {
