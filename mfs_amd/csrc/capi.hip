@@ -22,7 +22,7 @@ Filter1dFastLaunch g_fast_filter_wide[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes, carry_doubles; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
 hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s);
 extern Filter1dGradLaunch g_grad_table[11][5];  // filter1d_grad_inst.hip: [N <= 10][P <= 4]
@@ -360,7 +360,7 @@ int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const do
 // while chunk k's slice of out_moments travels to the host (2-D copy: B rows of chunk x 2N doubles).  MFS_HOST_CHUNKS
 // overrides (1 = one launch, copies afterwards).
 static int host_chunks(size_t moment_bytes, int T) {
-    int n = (int)(moment_bytes / ((size_t)64 << 20));
+    int n = (int)(moment_bytes / ((size_t)32 << 20));
     if (const char* e = getenv("MFS_HOST_CHUNKS")) n = atoi(e);
     if (n > 16) n = 16;
     if (n > T) n = T;
@@ -778,6 +778,24 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
     return MFS_OK;
 }
 
+// one launch over the steps [t0, t1) of the plan's run; `carry` ([B][carry_doubles], or null for a single launch over [0, T))
+// takes the state from one chunk to the next
+static int plan_nd_launch(mfs_plan_nd* p, const double* d_m0, int m0_batched, const double* d_mean0, const double* d_scale0,
+                          const double* d_ys, double* d_out_moments, double* d_out_means, double* d_out_scales,
+                          double* d_out_nell, int32_t* d_out_first_nan, int t0, int t1, double* carry, hipStream_t stream) {
+    mfs::FilterNdArgs a = p->args;
+    a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
+    a.out_mom = d_out_moments;
+    a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
+    a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
+    a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
+    a.t_begin = t0; a.t_end = t1; a.carry = carry;
+    const mfs::NdEntry& ke = mfs::g_nd_table[p->N];
+    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : p->hi_terms ? ke.launch_hi : ke.launch)(a, p->B, stream);
+    if (e != hipSuccess) return fail(MFS_EHIP, "N-D kernel launch: %s", hipGetErrorString(e));
+    return MFS_OK;
+}
+
 extern "C" int mfs_plan_nd_run(mfs_plan_nd* p, const double* d_m0, int m0_batched, const double* d_mean0,
                                const double* d_scale0, const double* d_ys, double* d_out_moments, double* d_out_means,
                                double* d_out_scales, double* d_out_nell, int32_t* d_out_first_nan, void* stream) {
@@ -787,16 +805,8 @@ extern "C" int mfs_plan_nd_run(mfs_plan_nd* p, const double* d_m0, int m0_batche
     if (p->mode != MFS_MODE_RAW && !d_mean0) return fail(MFS_EINVAL, "mean0 is required in central and scaled modes");
     if (p->mode == MFS_MODE_SCALED && !d_scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
     HIP_TRY(hipSetDevice(p->device));
-    mfs::FilterNdArgs a = p->args;
-    a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
-    a.out_mom = d_out_moments;
-    a.out_mean = (p->mode != MFS_MODE_RAW) ? d_out_means : nullptr;
-    a.out_scale = (p->mode == MFS_MODE_SCALED) ? d_out_scales : nullptr;
-    a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
-    const mfs::NdEntry& ke = mfs::g_nd_table[p->N];
-    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : p->hi_terms ? ke.launch_hi : ke.launch)(a, p->B, (hipStream_t)stream);
-    if (e != hipSuccess) return fail(MFS_EHIP, "mfs_plan_nd_run: %s", hipGetErrorString(e));
-    return MFS_OK;
+    return plan_nd_launch(p, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_out_moments, d_out_means, d_out_scales, d_out_nell,
+                          d_out_first_nan, 0, p->T, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int mfs_plan_nd_destroy(mfs_plan_nd* p) {
@@ -854,18 +864,41 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     if (mean0) h2d(d_mean0, mean0, nb * 2 * 8);
     if (scale0 && mode == MFS_MODE_SCALED) h2d(d_scale0, scale0, nb * 2 * 8);
     h2d(d_ys, ys, (size_t)B * T * ny * 8);
+    // with the moments streamed out, T is cut into chunks: chunk k's slice travels to the host (2-D copy: B rows of
+    // chunk x z doubles) on the copy stream while the kernel of chunk k + 1 runs; the per-replicate state crosses the
+    // launches through a carry block, so the bits are those of the single launch
+    const size_t mom_bytes = out_moments ? (size_t)B * T * Z * 8 : 0;
+    const int nchunks = (T > 0) ? host_chunks(mom_bytes, T) : 1;
+    const int chunk = (nchunks > 1) ? (T + nchunks - 1) / nchunks : T;
+    double* d_carry = nullptr;
+    if (nchunks > 1) alloc(&d_carry, (size_t)B * mfs::g_nd_table[N].carry_doubles * 8);
     if (e == hipSuccess) {
-        rc = mfs_plan_nd_run(plan, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn, s);
+        if (nchunks <= 1) {
+            rc = mfs_plan_nd_run(plan, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn, s);
+            if (rc == MFS_OK) d2h(out_moments, d_mom, mom_bytes);
+        } else {
+            const size_t pitch = (size_t)T * Z * 8;
+            for (int k = 0, t0 = 0; t0 < T && rc == MFS_OK && e == hipSuccess; ++k, t0 += chunk) {
+                const int t1 = (t0 + chunk < T) ? t0 + chunk : T;
+                rc = plan_nd_launch(plan, d_m0, m0_batched, d_mean0, d_scale0, d_ys, d_mom, d_means, d_scales, d_nell, d_fn,
+                                    t0, t1, d_carry, s);
+                if (rc != MFS_OK) break;
+                e = hipEventRecord(cx->ev[k], s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(cx->copy, cx->ev[k], 0);
+                if (e == hipSuccess && out_moments)
+                    e = hipMemcpy2DAsync(out_moments + (size_t)t0 * Z, pitch, d_mom + (size_t)t0 * Z, pitch,
+                                         (size_t)(t1 - t0) * Z * 8, (size_t)B, hipMemcpyDeviceToHost, cx->copy);
+            }
+        }
     }
     if (rc == MFS_OK) {
-        d2h(out_moments, d_mom, (size_t)B * T * Z * 8);
         d2h(out_means, d_means, (size_t)B * T * 2 * 8);
         d2h(out_scales, d_scales, (size_t)B * T * 2 * 8);
         d2h(out_nell, d_nell, (size_t)B * 8);
         d2h(out_first_nan, d_fn, (size_t)B * 4);
     }
-    const hipError_t es = hipStreamSynchronize(s);   // always: the pool blocks go back on return
-    if (e == hipSuccess) e = es;
+    const hipError_t es = hipStreamSynchronize(s), ec = hipStreamSynchronize(cx->copy);   // always: the pool blocks go back on return
+    if (e == hipSuccess) e = (es != hipSuccess) ? es : ec;
     if (rc != MFS_OK) return rc;
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MFS_ENOMEM : MFS_EHIP, "mfs_filter_nd: %s", hipGetErrorString(e));
     return MFS_OK;

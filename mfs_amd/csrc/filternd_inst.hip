@@ -6,7 +6,7 @@
 namespace mfs {
 
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes, carry_doubles; };
 NdEntry g_nd_table[8];
 
 template <int N, int TK>
@@ -21,7 +21,8 @@ template <int N>
 void reg_nd() {
     constexpr int d0 = NdTile<N, 0>::kDoubles, d1 = NdTile<N, 1>::kDoubles, d2 = NdTile<N, 2>::kDoubles;
     g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, &launch_nd<N, 2>, NdTile<N, 0>::S, NdTile<N, 0>::Z,
-                            (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) * 8};
+                            (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) * 8, NdTile<N, 0>::kCarry};
+    static_assert(NdTile<N, 0>::kCarry == NdTile<N, 1>::kCarry && NdTile<N, 0>::kCarry == NdTile<N, 2>::kCarry, "one carry layout");
     if constexpr (N < 7) reg_nd<N + 1>();
 }
 

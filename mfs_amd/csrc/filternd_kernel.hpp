@@ -45,6 +45,8 @@ __device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / d
 
 struct FilterNdArgs {
     int mode, T, B, stable;
+    int t_begin, t_end;       // the steps this launch takes (a chunk of [0, T)); the state crosses launches through `carry`
+    double* carry;            // [B][NdTile::kCarry]: moments, means / scales / nell / first-NaN / flags, eigenvector tiles (or null)
     int n_terms_used, D;      // coefficient block extent per variable (degree + 1)
     int n_factors, ny;        // likelihood = prod_f lik(kind_f, params_f, y[ycol_f], x[comp_f]);  ys is [B][T][ny]
     int fac_kind[2], fac_comp[2], fac_ycol[2];
@@ -165,6 +167,7 @@ struct NdTile {
     static constexpr int kDoubles = oGi + (kGatherLds ? nGi : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
     // moment-array tiles (free while a Jacobi runs)
+    static constexpr int kCarry = Z + 8 + 2 * NP * LD;   // per-replicate state between the chunk launches of one run
     static constexpr int oJs = (TK == 1) ? oW : oM;
     static_assert(S * S <= 2 * NPW * MLD, "Jacobi scratch must fit in the moment-array tiles");
 };
@@ -1128,31 +1131,39 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         const double* src = a.lik + (a.lik_batched ? (size_t)b * a.n_factors * 4 : 0);
         Sm[L::oLik + tid] = (tid < a.n_factors * 4) ? src[tid] : 0.0;
     }
+    // a later chunk of a run resumes from the carry: moments, scalars and the eigenvector tiles a warm start reads
+    const bool resume = (a.t_begin > 0) && (a.carry != nullptr);
+    double* cw = a.carry ? a.carry + (size_t)b * L::kCarry : nullptr;
     {
-        const double* src = a.m0 + (a.m0_batched ? (size_t)b * Z : 0);
+        const double* src = resume ? cw : a.m0 + (a.m0_batched ? (size_t)b * Z : 0);
         for (int e = tid; e < Z; e += 256) mom[e] = src[e];
+        if (resume) for (int e = tid; e < 2 * NP * LD; e += 256) Sm[L::oV + e] = cw[Z + 8 + e];
     }
     // every thread carries an identical copy of the block-uniform state (mean, scale, nell): they are all computed from
     // the same LDS values, so no broadcast is ever needed
     double mean0 = 0.0, mean1 = 0.0, nell = 0.0;
     double scale0 = 1.0, scale1 = 1.0;
-    if (!raw) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
-    if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
+    if (resume) {
+        mean0 = cw[Z]; mean1 = cw[Z + 1]; scale0 = cw[Z + 2]; scale1 = cw[Z + 3]; nell = cw[Z + 4];
+    } else {
+        if (!raw) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
+        if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
+    }
     double* red = Sm + L::oRed;
-    if (tid == 0) { red[16 * ZB] = 0.0; Sm[L::oMisc + 5] = __hiloint2double(0, -1); }   // flag slot 1: step of the first non-finite result (an int in the low word)
+    if (tid == 0) { red[16 * ZB] = 0.0; Sm[L::oMisc + 5] = resume ? cw[Z + 5] : __hiloint2double(0, -1); }   // flag slot 1: step of the first non-finite result (an int in the low word)
     // which matrices an update diagonalises: the components a likelihood factor reads
     int lik_mask = 0;
     for (int f = 0; f < a.n_factors; ++f) lik_mask |= 1 << a.fac_comp[f];
     const int ubeg = (lik_mask & 1) ? 0 : 1, uend = (lik_mask & 2) ? 2 : 1;
     __syncthreads();
-    bool dead = false;
-    int warm_mask = 0;
+    bool dead = resume ? (cw[Z + 6] != 0.0) : false;
+    int warm_mask = resume ? (int)cw[Z + 7] : 0;
     const double qnan = __builtin_nan("");
     const double* yrow = a.ys + (size_t)b * a.T * a.ny;
     double* bx = Sm + L::oBx;
     double* qs = Sm + L::oQs;
 
-    for (int t = 0; t < a.T; ++t) {
+    for (int t = a.t_begin; t < a.t_end; ++t) {
         if (!dead) {
             bool bad = false;
             // The two half-steps share ONE call site of the front end (inlined there: as a called function it saved and
@@ -1566,7 +1577,14 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
             a.out_scale[((size_t)b * a.T + t) * 2 + 1] = scale1;
         }
     }
-    if (tid == 0) {
+    if (a.t_end < a.T && cw) {      // not the last chunk: park the state
+        for (int e = tid; e < Z; e += 256) cw[e] = mom[e];
+        for (int e = tid; e < 2 * NP * LD; e += 256) cw[Z + 8 + e] = Sm[L::oV + e];
+        if (tid == 0) {
+            cw[Z] = mean0; cw[Z + 1] = mean1; cw[Z + 2] = scale0; cw[Z + 3] = scale1; cw[Z + 4] = nell;
+            cw[Z + 5] = Sm[L::oMisc + 5]; cw[Z + 6] = dead ? 1.0 : 0.0; cw[Z + 7] = (double)warm_mask;
+        }
+    } else if (tid == 0) {
         a.out_nell[b] = nell;
         if (a.out_first_nan) a.out_first_nan[b] = __double2loint(Sm[L::oMisc + 5]);
     }

@@ -189,3 +189,43 @@ def test_pipelined_host_entry_is_bit_identical_and_reuses_the_pool(monkeypatch):
     del keep, other
     _lib.check(_lib.lib().mfs_pool_trim(0))
     assert _lib.pool_stats(0)['device_bytes'] == 0
+
+
+@pytest.mark.parametrize('family,mode,route', [('tme_2', 'central', ''), ('tme_2', 'scaled', ''), ('tme_normal_2', 'central', ''),
+                                               ('tme_2', 'central', 'eigen')])
+def test_pipelined_nd_host_entry_is_bit_identical(monkeypatch, family, mode, route):
+    """mfs_filter_nd cuts T into chunks when the moments are streamed out (chunk k's slice is copied while chunk k + 1
+    computes); the per-replicate state -- moments, means, scales, NLL, first-NaN step, the eigenvector tiles a Jacobi warm
+    start reads -- crosses the launches through a carry block, so every output has the bits of the single launch: operator
+    path, scaled mode, Normal closure (warm-started Jacobi in the prediction) and the eigen-decomposition route of the
+    update."""
+    from mfs_amd.multi_dims import filtering as fnd, moments as mnd, ss_models as snd
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+        gram_and_hankel_indices_graded_lexico
+    N, T, B = 4, 37, 5
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, pmf, _ = snd.prey_predator(mi)
+    if family == 'tme_2':
+        fns, sig = mnd.sde_cond_moments_tme(drift, disp, dt, 2), 'multi-index'
+    else:
+        fns, sig = mnd.sde_cond_moments_tme_normal(drift, disp, dt, 2, mi), 'index'
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=9)
+    if route:
+        monkeypatch.setenv('MFS_ND_UPDATE', route)
+
+    def run():
+        if mode == 'central':
+            return fnd.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean, return_first_nan=True)
+        scale0 = np.sqrt(np.array([gs.cms[5], gs.cms[3]]))
+        return fnd.moment_filter_nd_scms((fns[2], sig), fns[4], pmf, ys, (mi, inds), gs.cms / np.prod(scale0 ** mi, axis=-1),
+                                         gs.mean, scale0)
+
+    monkeypatch.setenv('MFS_HOST_CHUNKS', '1')
+    ref = run()
+    assert np.all(np.isfinite(ref[-1 if mode == 'scaled' else 2]))
+    for chunks in ('2', '5', '37'):
+        monkeypatch.setenv('MFS_HOST_CHUNKS', chunks)
+        got = run()
+        for a, b in zip(ref, got):
+            npt.assert_array_equal(a, b)

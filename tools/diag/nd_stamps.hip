@@ -20,7 +20,7 @@ int run(int argc, char** argv) {
     hipMemcpy(dc, coef.data(), coef.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dl, lik.data(), 32, hipMemcpyHostToDevice);
     hipMemcpy(dm, m0.data(), z * 8, hipMemcpyHostToDevice); hipMemcpy(dmean, mean0.data(), 16, hipMemcpyHostToDevice);
     hipMemcpy(dys, ys.data(), ys.size() * 8, hipMemcpyHostToDevice); hipMemcpy(di, inds.data(), inds.size() * 4, hipMemcpyHostToDevice);
-    FilterNdArgs a{}; a.mode = 1; a.T = T; a.B = B; a.stable = 0; a.n_terms_used = nt; a.D = D; a.n_factors = 1; a.ny = 1;
+    FilterNdArgs a{}; a.mode = 1; a.T = T; a.t_begin = 0; a.t_end = T; a.B = B; a.stable = 0; a.n_terms_used = nt; a.D = D; a.n_factors = 1; a.ny = 1;
     a.fac_kind[0] = 0; a.fac_comp[0] = 0; a.fac_ycol[0] = 0; for (int k = 0; k < nd_rows<TK>(); ++k) { int ea = 0, eb = 0; for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) if (coef[(size_t)k * D * D + i * D + j] != 0.0) { if (i + 1 > ea) ea = i + 1; if (j + 1 > eb) eb = j + 1; } a.ext[k] = ea == 0 ? 0 : (ea | (eb << 8)); } a.coef = dc; a.lik = dl; a.inds = di; a.m0 = dm; a.m0_batched = 0; a.mean0 = dmean; a.ys = dys;
     a.out_mom = nullptr; a.out_mean = dmeans; a.out_nell = dnell; a.out_first_nan = nullptr;
     hipFuncSetAttribute(reinterpret_cast<const void*>(&filternd_kernel<N, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
