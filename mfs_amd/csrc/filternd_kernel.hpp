@@ -90,6 +90,11 @@ constexpr double kNdJacobiTol = MFS_ND_JACOBI_TOL;
 #endif
 // squared Frobenius size of the first-order eigenvector correction below which it replaces further sweeps (0: never)
 constexpr double kNdFinishX2 = MFS_ND_FINISH_X2;
+#ifndef MFS_ND_FINISH2_X2
+#define MFS_ND_FINISH2_X2 1e-9
+#endif
+// ... below which the SECOND-order correction does (its error is ~ ||X||^3: 3e-14 at 1e-9; 0: never)
+constexpr double kNdFinish2X2 = MFS_ND_FINISH2_X2;
 template <int TK> constexpr int nd_maxd() { return (TK == 2) ? 7 : 6; }   // per-variable extent bound of the coefficient blocks
 __device__ constexpr int kKap0[kNdTermsHi] = {0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6};
 __device__ constexpr int kKap1[kNdTermsHi] = {1, 0, 2, 1, 0, 3, 2, 1, 0, 4, 3, 2, 1, 0, 5, 4, 3, 2, 1, 0, 6, 5, 4, 3, 2, 1, 0};
@@ -591,6 +596,11 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
             int bin = (off > 0.0 && dia > 0.0) ? (int)(-log10(off / dia)) : 39;
             bin = bin < 0 ? 0 : bin > 39 ? 39 : bin;
             g_nd_hist[sweep < 8 ? sweep : 7][bin] += 1;
+            if (sweep == 2) {      // size of the first-order eigenvector correction at the first test after a warm start
+                int bx2 = (xsq > 0.0) ? (int)(-log10(xsq)) : 39;
+                bx2 = bx2 < 0 ? 0 : bx2 > 39 ? 39 : bx2;
+                g_nd_hist[6][bx2] += 1;
+            }
         }
 #endif
         if (!finite(off + dia)) { if (tid == 0) flags[0] = 1.0; break; }
@@ -632,6 +642,79 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
             for (int e = tid; e < nm * S * S; e += nthr) {
                 const int m = mbeg + e / (S * S), f = e % (S * S), k = f / S, j = f - k * S;
                 V[m * NP * LD + k * LD + j] += (m == 0) ? A[k * LD + j] : T1[k * S + j];
+            }
+            for (int e = tid; e < nm * S; e += nthr) K[(mbeg + e / S) * NP * LD + (e % S) * (LD + 1)] = cs[e];
+            break;
+        }
+        if (xsq <= kNdFinish2X2) {
+            // The same one order further, U = I + X + Y with (Rayleigh-Schroedinger, E_jj = 0)
+            //   Y_ij = (E X)_ij / (d_j - d_i)  (i != j),   Y_jj = -1/2 sum_k X_kj^2,   (E X)_ij = sum_k X_ik (d_k - d_i) X_kj,
+            //   lambda_j = d_j + sum_k (d_j - d_k) X_kj^2 + sum_k X_kj (E X)_kj,
+            // orthogonal and diagonalising up to ||X||^3 <= 3e-14: two S x S x S products per matrix, and it applies
+            // right after the SECOND sweep of a warm-started run (||X||^2 is 1e-8 ... 1e-11 there, 1e-14 would need the
+            // third sweep -- S - 1 more rounds of rotations with two barriers each).
+            double* Z0 = A;                  // [S][LD-strided] (m = 0)
+            double* Z1 = Sm + L::oJs;        // [S][S]          (m = 1)
+            double* yd = Sm + L::oRed;       // [nm][S] diagonal of Y (the test's scratch slots are free; the flag slot lies beyond)
+            static_assert(2 * S <= 16 * L::ZB, "diagonal corrections must stay below the flag slot of the reduction tile");
+            for (int e = tid; e < nm * S * S; e += nthr) {      // X over the off-diagonal of K (the diagonal stays)
+                double* Kk = K + (mbeg + e / (S * S)) * NP * LD;
+                const int f = e % (S * S), i = f / S, j = f - i * S;
+                if (i != j) Kk[i * LD + j] = Kk[i * LD + j] / (Kk[j * (LD + 1)] - Kk[i * (LD + 1)]);
+            }
+            __syncthreads();
+            for (int e = tid; e < nm * S * S; e += nthr) {      // Z_m = E_m X_m, Y_jj
+                const int m = mbeg + e / (S * S), f = e % (S * S), i = f / S, j = f - i * S;
+                const double* Kk = K + m * NP * LD;
+                const double di = Kk[i * (LD + 1)];
+                double acc = 0.0, ysum = 0.0;
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const double xik = (k == i) ? 0.0 : Kk[i * LD + k], xkj = (k == j) ? 0.0 : Kk[k * LD + j];
+                    acc = fma(xik * (Kk[k * (LD + 1)] - di), xkj, acc);
+                    ysum = fma(xkj, xkj, ysum);
+                }
+                if (m == 0) Z0[i * LD + j] = acc; else Z1[i * S + j] = acc;
+                if (i == 0) yd[(m - mbeg) * S + j] = -0.5 * ysum;
+            }
+            __syncthreads();
+            for (int e = tid; e < nm * S; e += nthr) {          // third-order eigenvalues, parked in the rotation records
+                const int m = mbeg + e / S, j = e % S;
+                const double* Kk = K + m * NP * LD;
+                const double dj = Kk[j * (LD + 1)];
+                double acc = dj;
+                for (int k = 0; k < S; ++k) {
+                    const double x = (k == j) ? 0.0 : Kk[k * LD + j];
+                    const double z = (m == 0) ? Z0[k * LD + j] : Z1[k * S + j];
+                    acc = fma((dj - Kk[k * (LD + 1)]) * x, x, acc);
+                    acc = fma(x, z, acc);
+                }
+                cs[e] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < nm * S * S; e += nthr) {      // off-diagonal of U - I in place of X
+                const int m = mbeg + e / (S * S), f = e % (S * S), i = f / S, j = f - i * S;
+                double* Kk = K + m * NP * LD;
+                if (i != j) {
+                    const double z = (m == 0) ? Z0[i * LD + j] : Z1[i * S + j];
+                    Kk[i * LD + j] += z / (Kk[j * (LD + 1)] - Kk[i * (LD + 1)]);
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < nm * S * S; e += nthr) {      // T_m = V_m (U_m - I)
+                const int m = mbeg + e / (S * S), f = e % (S * S), k = f / S, j = f - k * S;
+                const double* Kk = K + m * NP * LD;
+                const double* Vk = V + m * NP * LD;
+                const double yjj = yd[(m - mbeg) * S + j];
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < S; ++i) acc = fma(Vk[k * LD + i], (i == j) ? yjj : Kk[i * LD + j], acc);
+                if (m == 0) Z0[k * LD + j] = acc; else Z1[k * S + j] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < nm * S * S; e += nthr) {
+                const int m = mbeg + e / (S * S), f = e % (S * S), k = f / S, j = f - k * S;
+                V[m * NP * LD + k * LD + j] += (m == 0) ? Z0[k * LD + j] : Z1[k * S + j];
             }
             for (int e = tid; e < nm * S; e += nthr) K[(mbeg + e / S) * NP * LD + (e % S) * (LD + 1)] = cs[e];
             break;
