@@ -61,11 +61,17 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = 'benes_bernoulli_N15_T1000_B4096_central_tme3'
 # (workload, B override, label): short runs reported under `other_workloads` by the default single-GPU run
 OTHER_WORKLOADS = [
+    ('benes_bernoulli_N7_T100_B4096_central_tme3', 0, 'config1_size_B4096'),
+    # config 2 in the other two representations (with the divergence counts) and with the Normal closure
+    ('benes_bernoulli_N15_T1000_B4096_raw_tme3', 0, 'config2_raw'),
+    ('benes_bernoulli_N15_T1000_B4096_scaled_tme3', 0, 'config2_scaled'),
+    ('benes_bernoulli_N15_T1000_B4096_central_tme_normal3', 0, 'config2_tme_normal3'),
     ('ou_gaussian_N15_T1000_B1024_central', 0, 'config3_N15'),
     ('ou_gaussian_N25_T1000_B1024_central', 0, 'config3_N25'),
     ('well_poisson_N7_T1000_B131072_central_tme_normal2', 0, 'config4_shard_B131072'),
     ('prey_predator_N6_T500_B512_central_tme2', 0, 'config5_B512'),
     ('prey_predator_N6_T500_B512_central_tme2', 128, 'config5_4gpu_shard_B128'),
+    ('prey_predator_N6_T500_B512_central_tme_normal2', 0, 'config5_tme_normal2'),
 ]
 
 
@@ -530,7 +536,8 @@ def other_workloads(comm, device):
             s = summarise(w, res, 2, 1, True)
             out[label] = {'workload': name, 'replicates': w.B, 'T': w.T, 'N': w.N, 'kernel_ms': s['kernel_ms'],
                           'ms_per_step': s['ms_per_step'], 'value': s['value'], 'nominal_value': s['nominal_value'],
-                          'live_fraction': s['live_fraction'], 'unit': 'filter-steps/s', 'kernel': w.kernel,
+                          'live_fraction': s['live_fraction'], 'replicates_alive_at_T': int(res['alive']),
+                          'unit': 'filter-steps/s', 'kernel': w.kernel,
                           'hbm_gbs_algorithmic': s['hbm_gbs']}
             if label == 'config5_B512':     # the reference-shaped N-D entry point on the same data, host arrays in and out
                 out[label]['end_to_end_ms'] = end_to_end(w)['end_to_end_ms']
