@@ -57,6 +57,9 @@ WORKLOADS = {
     # BASELINE config 5 (d = 2): per-GPU shard of the 512-replicate batch is set with --B (128 on 4 GPUs)
     'prey_predator_N6_T500_B512_central_tme2': ('prey', 6, 500, 512, 'central', 'tme_2'),
     'prey_predator_N6_T500_B512_central_tme_normal2': ('prey', 6, 500, 512, 'central', 'tme_normal_2'),
+    # the order the reference's CPU script runs (dardel/run_prey_predator_mf.sh:29-30: --N=5, tme_2 and tme_normal_2)
+    'prey_predator_N5_T500_B512_central_tme2': ('prey', 5, 500, 512, 'central', 'tme_2'),
+    'prey_predator_N5_T500_B512_central_tme_normal2': ('prey', 5, 500, 512, 'central', 'tme_normal_2'),
 }
 DEFAULT_WORKLOAD = 'benes_bernoulli_N15_T1000_B4096_central_tme3'
 # (workload, B override, label): short runs reported under `other_workloads` by the default single-GPU run
