@@ -179,3 +179,45 @@ def test_per_replicate_parameters_on_the_nd_path():
     assert len({float(v) for v in ne}) == B
     with pytest.raises(ValueError):      # per-replicate parameters need a replicate axis on ys
         filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf_b(off), ys[0], (mi, inds), gs.cms, gs.mean)
+
+
+def test_narrow_likelihood_takes_the_checked_fallback(monkeypatch):
+    """A Gaussian measurement much narrower than the predicted law (sd 0.12 against a prior spread of ~0.45; much below that the
+    9-node rule itself breaks down and the oracle poisons too): the Chebyshev
+    interpolant of the likelihood on the spectrum's interval does not converge within its 32 nodes, the coefficient-tail
+    check says so, and the update falls back to diagonalising K_k -- silently to the caller, visibly here: the outputs are
+    BIT-identical to a run with the eigen-decomposition route forced, and both match the oracle."""
+    sd = 0.12
+    np.random.seed(7)
+    T2 = 25
+    ys_2d = 0.1 + 0.05 * np.random.randn(T2, 2)
+    d, N, order, m0, var0 = 2, 3, 2, 0.1, 0.2
+    mi = generate_graded_lexico_multi_indices(d, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, d)
+    fnd = moments.sde_cond_moments_tme(drift, dispersion_2d, dt, order)
+    cms0 = np.array([central_moments_mvn_kan(var0 * np.eye(d), m) for m in mi])
+    mean0 = m0 * np.ones(d)
+
+    def pdf(y, x):
+        return math.prod(stats.norm_pdf(y, x, sd))
+
+    got = filtering.moment_filter_nd_cms((fnd[1], 'multi-index'), fnd[3], pdf, ys_2d, (mi, inds), cms0, mean0)
+    monkeypatch.setenv('MFS_ND_UPDATE', 'eigen')
+    eig = filtering.moment_filter_nd_cms((fnd[1], 'multi-index'), fnd[3], pdf, ys_2d, (mi, inds), cms0, mean0)
+    monkeypatch.delenv('MFS_ND_UPDATE')
+    assert np.all(np.isfinite(got[2]))
+    # the first update (widest predicted law) is the one whose interpolant cannot converge: from there on the two runs share
+    # every bit only if the default route really took the fallback at that step
+    different = [int(np.argmax(np.any(a != b, axis=tuple(range(1, a.ndim))))) if np.any(a != b) else -1 for a, b in
+                 zip(got[:2], eig[:2])]
+    print('first step at which the default and the forced-eigen runs differ (moments, means):', different)
+    npt.assert_array_equal(got[0][0], eig[0][0])
+    npt.assert_array_equal(got[1][0], eig[1][0])
+    npt.assert_allclose(got[2], eig[2], rtol=1e-10)
+    _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(lambda x: [-x[0] / ell, -x[1] / ell],
+                                                          lambda x: [[b_const, 0], [0, b_const]], d, dt, order, mi)
+    rc = omd.moment_filter_nd_cms((ocms, 'multi-index'), omean, lambda y, x: float(np.prod(om.norm_pdf(y, x, sd))), ys_2d,
+                                  (mi, inds), cms0, mean0)
+    npt.assert_allclose(got[2], rc[2], rtol=1e-8)
+    npt.assert_allclose(got[1], rc[1], rtol=1e-7, atol=1e-10)
+    npt.assert_allclose(got[0], rc[0], rtol=1e-6, atol=1e-12)
