@@ -215,3 +215,30 @@ def test_tme_order_3_scaled_mode_and_wide_table():
     npt.assert_allclose(nell_s, nell_c, rtol=1e-6)
     npt.assert_allclose(means_s, means_c, rtol=1e-6)
     npt.assert_allclose(scales ** 2, np.stack([cmss[:, :, 5], cmss[:, :, 3]], axis=-1), rtol=1e-6)
+
+
+@pytest.mark.parametrize('family', ['tme_2', 'tme_normal_2'])
+def test_maximum_order_N7(family):
+    """The largest order the d = 2 kernels are built for: N = 7 (s = 28 Gram size, z = 105 moments, 784 tensor nodes) -- its
+    own code paths: two elimination streams in the front end (3 s > 64 lanes), strided Jacobi rounds without the index table,
+    gather indices from global memory.  Against the oracle, a few steps."""
+    N, T, B = 7, 6, 2
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    assert mi.shape[0] == 105 and inds.shape[1] == 28
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    _, _, ogs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    ys, _ = synth.prey_predator_batch(B, T, dt, seed=70)
+    if family == 'tme_2':
+        fns, sig = moments.sde_cond_moments_tme(drift, disp, dt, 2), 'multi-index'
+        ofns = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, 2, mi)
+        ocms, omean = ofns[1], ofns[2]
+    else:
+        fns, sig = moments.sde_cond_moments_tme_normal(drift, disp, dt, 2, mi), 'index'
+        _, ocms, omean = tme_sympy.sde_cond_moments_normal_nd(odrift, odisp, 2, dt, 2, mi)
+    cmss, means, nell = filtering.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
+    assert cmss.shape == (B, T, 105) and np.all(np.isfinite(nell))
+    rc = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
+    npt.assert_allclose(nell[0], rc[2], rtol=1e-6)
+    npt.assert_allclose(means[0], rc[1], rtol=1e-6)
+    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6 if family == 'tme_2' else 1e-4)
