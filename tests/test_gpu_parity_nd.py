@@ -242,3 +242,15 @@ def test_maximum_order_N7(family):
     npt.assert_allclose(nell[0], rc[2], rtol=1e-6)
     npt.assert_allclose(means[0], rc[1], rtol=1e-6)
     _assert_moments(cmss[0], rc[0], mi, rtol=1e-6 if family == 'tme_2' else 1e-4)
+
+
+def test_nd_empty_batch_and_zero_steps():
+    """Empty inputs behave like the 1-D entry points': B = 0 gives empty outputs, T = 0 gives the initial state's shapes and a
+    zero NLL (a scan over no steps)."""
+    mi, inds, dt, gs, fns, pmf, *_ = _setup(3)
+    ys, _ = synth.prey_predator_batch(3, 10, dt, seed=2)
+    m, means, nell = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys[:0], (mi, inds), gs.cms, gs.mean)
+    assert m.shape == (0, 10, mi.shape[0]) and means.shape == (0, 10, 2) and nell.shape == (0,)
+    m, means, nell = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys[:, :0], (mi, inds), gs.cms, gs.mean)
+    assert m.shape == (3, 0, mi.shape[0]) and means.shape == (3, 0, 2)
+    npt.assert_array_equal(nell, np.zeros(3))
