@@ -221,3 +221,30 @@ def test_narrow_likelihood_takes_the_checked_fallback(monkeypatch):
     npt.assert_allclose(got[2], rc[2], rtol=1e-8)
     npt.assert_allclose(got[1], rc[1], rtol=1e-7, atol=1e-10)
     npt.assert_allclose(got[0], rc[0], rtol=1e-6, atol=1e-12)
+
+
+def test_two_measurements_of_one_component():
+    """Two likelihood factors that read the SAME state component (two sensors on x_0, none on x_1): one wave evaluates the
+    product, the other component's h is e_0.  Against the oracle."""
+    np.random.seed(11)
+    T2 = 30
+    ys_2d = 0.2 + np.random.randn(T2, 2)
+    d, N, order, m0, var0 = 2, 3, 2, 0.1, 0.2
+    mi = generate_graded_lexico_multi_indices(d, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, d)
+    fnd = moments.sde_cond_moments_tme(drift, dispersion_2d, dt, order)
+    cms0 = np.array([central_moments_mvn_kan(var0 * np.eye(d), m) for m in mi])
+    mean0 = m0 * np.ones(d)
+
+    def pdf(y, x):
+        return stats.norm_pdf(y[0], x[0], 1.) * stats.norm_pdf(y[1], x[0], 2.)
+
+    got = filtering.moment_filter_nd_cms((fnd[1], 'multi-index'), fnd[3], pdf, ys_2d, (mi, inds), cms0, mean0)
+    _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(lambda x: [-x[0] / ell, -x[1] / ell],
+                                                          lambda x: [[b_const, 0], [0, b_const]], d, dt, order, mi)
+    rc = omd.moment_filter_nd_cms((ocms, 'multi-index'), omean,
+                                  lambda y, x: float(om.norm_pdf(y[0], x[0], 1.) * om.norm_pdf(y[1], x[0], 2.)), ys_2d,
+                                  (mi, inds), cms0, mean0)
+    npt.assert_allclose(got[2], rc[2], rtol=1e-9)
+    npt.assert_allclose(got[1], rc[1], rtol=1e-8, atol=1e-11)
+    npt.assert_allclose(got[0], rc[0], rtol=1e-6, atol=1e-10)
