@@ -432,3 +432,25 @@ def test_poisson_counts_beyond_the_log_factorial_table():
         assert both[:first_large + 1].all()
         npt.assert_allclose(means[b][both], r_means[both], rtol=RTOL, atol=1e-9)
         _assert_moments(cmss[b][both], r_cmss[both])
+
+
+def test_non_finite_measurement_poisons_from_that_step():
+    """A NaN measurement (a missing value handed through) makes the likelihood NaN: the replicate is NaN from that step on, as
+    in the reference's scan, its neighbours are untouched, and first_nan reports the step.  Gaussian measurements, OU model
+    (the Bernoulli pmf `y ? p : 1 - p` would silently read NaN as 0)."""
+    m = om.ou_gaussian(5)
+    T, B = 30, 3
+    ys, _ = synth.ou_gaussian_batch(B, T, seed=2)
+    ys[1, 11] = np.nan
+    from mfs_amd import stats
+    F, Sigma = m['F'], m['Sigma']
+    _, cond_cms, _, cond_mean, _ = moments.sde_cond_moments_normal(lambda x: F * x, lambda x: Sigma)
+    mm, means, nell, fn = filtering.moment_filter_cms(cond_cms, lambda x: F * x, lambda y, x: stats.norm_pdf(y, x, 1.),
+                                                      m['cms0'], m['mean0'], ys, return_first_nan=True)
+    assert list(fn) == [-1, 11, -1]
+    assert np.all(np.isfinite(mm[1, :11])) and np.all(np.isnan(mm[1, 11:])) and np.isnan(nell[1])
+    for b in (0, 2):
+        r = o.moment_filter_cms(m['cond_cms'], m['cond_mean'], m['pdf'], m['cms0'], m['mean0'], ys[b])
+        npt.assert_allclose(nell[b], r[2], rtol=RTOL)
+    r = o.moment_filter_cms(m['cond_cms'], m['cond_mean'], m['pdf'], m['cms0'], m['mean0'], ys[1])
+    assert np.all(np.isfinite(r[1][:11])) and np.all(np.isnan(r[1][11:]))
