@@ -248,3 +248,22 @@ def test_two_measurements_of_one_component():
     npt.assert_allclose(got[2], rc[2], rtol=1e-9)
     npt.assert_allclose(got[1], rc[1], rtol=1e-8, atol=1e-11)
     npt.assert_allclose(got[0], rc[0], rtol=1e-6, atol=1e-10)
+
+
+def test_nan_measurement_poisons_the_nd_replicate_from_that_step():
+    """A NaN in the measurement row: the Chebyshev samples are NaN, the tail check fails, the fallback's likelihood is NaN too,
+    and the replicate is NaN from that step on (first_nan says which); the other replicate of the batch is untouched."""
+    ys, ys_2d = _measurements()
+    d, N, order, m0, var0 = 2, 3, 2, 0.1, 0.2
+    mi = generate_graded_lexico_multi_indices(d, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, d)
+    fnd = moments.sde_cond_moments_tme(drift, dispersion_2d, dt, order)
+    cms0 = np.array([central_moments_mvn_kan(var0 * np.eye(d), m) for m in mi])
+    mean0 = m0 * np.ones(d)
+    ysB = np.stack([ys_2d[:40], ys_2d[:40]])
+    ysB[1, 13, 1] = np.nan
+    m, means, nell, fn = filtering.moment_filter_nd_cms((fnd[1], 'multi-index'), fnd[3], measurement_cond_pdf_2d, ysB,
+                                                        (mi, inds), cms0, mean0, return_first_nan=True)
+    assert list(fn) == [-1, 13]
+    assert np.all(np.isfinite(m[1, :13])) and np.all(np.isnan(m[1, 13:])) and np.isnan(nell[1]) and np.isfinite(nell[0])
+    npt.assert_array_equal(m[0, :13], m[1, :13])
