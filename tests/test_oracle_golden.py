@@ -1,0 +1,96 @@
+"""CPU suite: the checkers against the frozen fixtures under tests/golden/ (no GPU, no reference).
+
+  * the NumPy/LAPACK oracle reproduces the numbers it froze (a change to oracle/ that moves them is caught here, before any
+    GPU parity test is read against the fixtures);
+  * the oracle and its C port against the 80-digit exact-arithmetic trajectories of the headline filter (N = 15): how far a
+    correct fp64 implementation of the reference's algorithm sits from the truth -- the yardstick the GPU parity tests use
+    where two fp64 implementations disagree (tests/test_gpu_golden.py, tests/test_gpu_envelope.py).
+"""
+import math
+import os
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from mfs_amd import synth
+from oracle import c_oracle, multi_dims as omd, models as om, one_dim as o, parity, tme_sympy
+
+
+def _load(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.fail(f'{name} is missing: see tests/golden/make_filter_golden.py / make_exact_golden.py')
+    return np.load(path)
+
+
+def _unpack(bits, T):
+    return np.unpackbits(bits, axis=1)[:, :T].astype(np.float64)
+
+
+def test_oracle_reproduces_config1_fixture(golden_dir):
+    g = _load(golden_dir, 'filter_cfg1.npz')
+    N, T, B = int(g['N']), int(g['T']), int(g['B'])
+    odt, _, oic, odrift, odisp, _, opmf = om.benes_bernoulli(N)
+    ora = tme_sympy.sde_cond_moments_tme_1d(odrift, odisp, odt, int(g['tme_order']), 2 * N)
+    ys = _unpack(g['ys_bits'], T)
+    npt.assert_array_equal(ys, synth.benes_bernoulli_batch(B, T, odt, seed=int(g['seed']))[0])
+    for b in range(B):
+        m, nell = o.moment_filter_rms(ora[0], opmf, oic.rms, ys[b])
+        npt.assert_allclose(nell, g['raw_nell'][b], rtol=1e-12)
+        npt.assert_allclose(m, g['raw_moments'][b], rtol=1e-9, atol=1e-300)
+        m, means, nell = o.moment_filter_cms(ora[1], ora[3], opmf, oic.cms, oic.mean, ys[b])
+        npt.assert_allclose(nell, g['central_nell'][b], rtol=1e-12)
+        npt.assert_allclose(means, g['central_means'][b], rtol=1e-10, atol=1e-14)
+        m, means, scales, nell = o.moment_filter_scms(ora[2], ora[4], opmf, oic.scms, oic.mean, math.sqrt(oic.variance), ys[b])
+        npt.assert_allclose(nell, g['scaled_nell'][b], rtol=1e-12)
+        npt.assert_allclose(scales, g['scaled_scales'][b], rtol=1e-10)
+
+
+def test_oracle_reproduces_config5_fixture_slice(golden_dir):
+    """Prey--predator N = 6: the first 20 steps of replicate 0 (the oracle takes ~0.05 s per step here)."""
+    g = _load(golden_dir, 'filter_cfg5.npz')
+    N, T = int(g['N']), 20
+    mi = omd.generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = omd.gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, gs, odrift, odisp, _, opmf = omd.prey_predator(mi)
+    _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, 2, mi)
+    ys = _unpack(g['ys_bits'], int(g['T']))
+    npt.assert_array_equal(ys, synth.prey_predator_batch(int(g['B']), int(g['T']), dt, seed=int(g['seed']))[0])
+    m, means, nell = omd.moment_filter_nd_cms((ocms, 'multi-index'), omean, opmf, ys[0, :T], (mi, inds), gs.cms, gs.mean)
+    npt.assert_allclose(means, g['tme2_means'][0, :T], rtol=1e-10)
+    npt.assert_allclose(m[:, 5], g['tme2_var0'][0, :T], rtol=1e-8)
+    steps = g['moment_steps'][g['moment_steps'] < T]
+    err = parity.rel_err(m[steps], g['tme2_moments'][0, :len(steps)], parity.natural_magnitude_nd(g['tme2_moments'][0, :len(steps)], mi) * 1e-2)
+    assert np.nanmax(err) <= 1e-8
+
+
+def test_cpu_implementations_against_exact_arithmetic(golden_dir):
+    """Benes--Bernoulli N = 15, TME-3, the first 6 of the 64 replicates x 300 steps of filter_cfg2_exact_B64.npz: the C port
+    on all of them, the NumPy oracle on two (it takes ~6 s per replicate).  On the steps an implementation is finite it is
+    within 1e-6 of the exact NLL / mean and 1e-4 of the exact variance -- and in exact arithmetic none of these replicates
+    poisons, which an fp64 implementation may (that is why the GPU tests do not take either CPU implementation as the truth)."""
+    e = _load(golden_dir, 'filter_cfg2_exact_B64.npz')
+    N, T, B = int(e['N']), int(e['T']), 6
+    assert N == 15 and np.all(e['central_first_nan'][:B] == -1)
+    odt, _, oic, odrift, odisp, _, opmf = om.benes_bernoulli(N)
+    ys = _unpack(e['ys_bits'], T)[:B]
+    npt.assert_array_equal(ys, synth.benes_bernoulli_batch(int(e['batch_B']), int(e['batch_T']), odt, seed=int(e['seed']))[0][:B, :T])
+    tab = tme_sympy.operator_tables_1d(odrift, odisp, odt, 3, 'tanh')
+    cm, cmeans, _, cnell = c_oracle.filter_1d(1, N, ys, oic.cms, oic.mean, None, 0, 1, 6, tab, 1.0, 0, np.array([0., 0., 0., 0.2]))
+    sd = np.sqrt(e['central_variances'][:B])
+    for b in range(B):
+        ok = np.isfinite(cmeans[b])
+        assert ok.sum() >= 60
+        assert np.max(np.abs(cmeans[b][ok] - e['central_means'][b][ok]) / np.maximum(np.abs(e['central_means'][b][ok]), sd[b][ok])) <= 1e-6
+        assert np.max(parity.rel_err(cm[b][ok, 2], e['central_variances'][b][ok])) <= 1e-4
+        if np.isfinite(cnell[b]):
+            npt.assert_allclose(cnell[b], e['central_nell'][b], rtol=1e-8)
+    ora = tme_sympy.sde_cond_moments_tme_1d(odrift, odisp, odt, 3, 2 * N)
+    for b in (0, 1):
+        m, means, nell = o.moment_filter_cms(ora[1], ora[3], opmf, oic.cms, oic.mean, ys[b])
+        ok = np.isfinite(means)
+        assert ok.sum() >= 60
+        assert np.max(np.abs(means[ok] - e['central_means'][b][ok]) / np.maximum(np.abs(e['central_means'][b][ok]), sd[b][ok])) <= 1e-5
+        if np.isfinite(nell):
+            npt.assert_allclose(nell, e['central_nell'][b], rtol=1e-8)
