@@ -229,3 +229,45 @@ def test_pipelined_nd_host_entry_is_bit_identical(monkeypatch, family, mode, rou
         got = run()
         for a, b in zip(ref, got):
             npt.assert_array_equal(a, b)
+
+
+def test_host_entry_points_are_reentrant_across_threads():
+    """SURVEY 8b "Threading": ctypes releases the GIL during a call and the ABI is re-entrant -- each call leases its own
+    stream / event context and its own blocks from the (mutex-guarded) pool.  Four Python threads filter different batches
+    at once, 1-D and N-D mixed; every result has the bits of the same call made alone."""
+    import threading
+    from mfs_amd.multi_dims import filtering as fnd, moments as mnd, ss_models as snd
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+        gram_and_hankel_indices_graded_lexico
+    N = 8
+    dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.benes_bernoulli(N)
+    _, c, _, mu, _ = moments.sde_cond_moments_tme(drift, dispersion, dt, 3)
+    mi = generate_graded_lexico_multi_indices(2, 5)
+    inds = gram_and_hankel_indices_graded_lexico(3, 2)
+    dt2, _, _, gs, drift2, disp2, _, pmf2, _ = snd.prey_predator(mi)
+    fns2 = mnd.sde_cond_moments_tme(drift2, disp2, dt2, 2)
+    jobs = []
+    for k in range(3):
+        ys, _ = synth.benes_bernoulli_batch(40 + 17 * k, 120, dt, seed=30 + k)
+        jobs.append(lambda ys=ys: filtering.moment_filter_cms(c, mu, pmf, ic.cms, ic.mean, ys))
+    ys2, _ = synth.prey_predator_batch(6, 60, dt2, seed=3)
+    jobs.append(lambda: fnd.moment_filter_nd_cms((fns2[1], 'multi-index'), fns2[3], pmf2, ys2, (mi, inds), gs.cms, gs.mean))
+    alone = [job() for job in jobs]
+    for _ in range(3):
+        out, errs = [None] * len(jobs), []
+
+        def run(i):
+            try:
+                out[i] = jobs[i]()
+            except Exception as e:   # noqa: BLE001 -- reported below
+                errs.append(e)
+
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errs, errs
+        for a, b in zip(alone, out):
+            for x, y in zip(a, b):
+                npt.assert_array_equal(x, y)
