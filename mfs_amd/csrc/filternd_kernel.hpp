@@ -121,11 +121,16 @@ struct NdTile {
     static constexpr int oK = oA + NP * LD;          // [2][NP][LD]
     static constexpr int oV = oK + 2 * NP * LD;      // [2][NP][LD]
     static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
-    static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] node weights (Normal closures)
-    static constexpr int oLam = oW + ((TK == 1) ? ((R + 1) & ~1) : 0); // [2][NP]
+    // Normal closures integrate over s^2 eigen-nodes (weights W, coordinates lam) or -- when the integrand's degree allows --
+    // over an NCP x NCP Chebyshev grid with the weights Omega of the same bilinear form (kNcpMax bounds NCP)
+    static constexpr int kNcpMax = 24;
+    static constexpr int LS = (NP > kNcpMax) ? NP : kNcpMax;           // stride of the two coordinate lists
+    static constexpr int nWt = (R > kNcpMax * kNcpMax) ? R : kNcpMax * kNcpMax;
+    static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] / [NCP][NCP] node weights (Normal closures)
+    static constexpr int oLam = oW + ((TK == 1) ? ((nWt + 1) & ~1) : 0); // [2][LS]
     static constexpr int ZB = (Z + 15) / 16;         // batches of 16 moments in the transposing reduction
     static constexpr int RW = 16 * ZB + 6;           // reduction row: moments (padded), flag, 5 scalar sums
-    static constexpr int oRed = oLam + 2 * NP;       // [4 waves x 4 DPP rows][RW]
+    static constexpr int oRed = oLam + 2 * LS;       // [4 waves x 4 DPP rows][RW]
     static constexpr int nRed = (TK == 1) ? 16 * RW : 16 * ZB + 16;   // operator path: Jacobi test scratch + the flag slot at [16 ZB]
     static constexpr int kTerms = nd_terms<TK>(), kRows = nd_rows<TK>(), kMaxD = nd_maxd<TK>();
     static constexpr bool kOperator = (TK != 1);     // operator-table prediction (TK = 0, 2) or Normal closure (TK = 1)
@@ -135,7 +140,8 @@ struct NdTile {
     // Tournament index tables, built once per launch: which rows / columns a work item touches in round r depends on
     // (r, item) only, and recomputing it cost ~50 integer instructions per thread per round next to ~30 flops.
     //   KT[r][P * HP + Q] = p1 | p2 << 8 | q1 << 16 | q2 << 24  (u32)
-    static constexpr bool kTables = (2 * HP * HP <= 256) && (2 * S * HP <= 512);
+    // (not for Normal closures: their Jacobi is a fallback now -- strided rounds -- and the 10 KB go to the Chebyshev-grid tables)
+    static constexpr bool kTables = (TK != 1) && (2 * HP * HP <= 256) && (2 * S * HP <= 512);
     static constexpr int oIdxK = oMisc + 8;
     static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
     // bilinear-form path: Krylov tiles, the moment array of the rule and its shifted copy, re-centred coefficients
@@ -168,10 +174,19 @@ struct NdTile {
     // per-rule gather then makes no global-memory round trip
     static constexpr int oGi = oFf + (kOperator ? P * FFS : 0);
     static constexpr int nGi = (3 * S * S + 3) / 4;
-    static constexpr bool kGatherLds = (oGi + nGi) * 8 <= 80 * 1024;
-    static constexpr int kDoubles = oGi + (kGatherLds ? nGi : 0);
+    static constexpr int nChebGrid = (TK == 1) ? 24 * 24 + 24 : 0;       // (kNcpMax^2 + kNcpMax, laid out after the gather table)
+    static constexpr bool kGatherLds = (oGi + nGi + nChebGrid) * 8 <= 80 * 1024;
+    static constexpr int kDoubles0 = oGi + (kGatherLds ? nGi : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
     // moment-array tiles (free while a Jacobi runs)
+    // Chebyshev-grid rule of a Normal closure: the transform table D[a][p] = (2 - [a = 0]) / NCP cos(pi a (p + 1/2) / NCP), the
+    // grid's cosines, and the vectors T_a(Khat_k) e_0 -> l_p(X_k) e_0 ([2][NCP][NP], in the Krylov / moment-array tiles,
+    // which a Normal-closure prediction does not otherwise use)
+    static constexpr int oChD = kDoubles0;
+    static constexpr int oChG = oChD + ((TK == 1) ? kNcpMax * kNcpMax : 0);
+    static constexpr int kDoubles = oChG + ((TK == 1) ? kNcpMax : 0);
+    static constexpr int oU = oPK;
+    static_assert(2 * kNcpMax * NP <= 2 * NPW * NP + 2 * NPW * MLD, "Chebyshev-grid vectors must fit in the Krylov and moment-array tiles");
     static constexpr int kCarry = Z + 8 + 2 * NP * LD;   // per-replicate state between the chunk launches of one run
     static constexpr int oJs = (TK == 1) ? oW : oM;
     static_assert(S * S <= 2 * NPW * MLD, "Jacobi scratch must fit in the moment-array tiles");
@@ -772,7 +787,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
             __syncthreads();
             // One straight-line section per thread: its 2x2 block of A <- J^T A J and its two eigenvector row-pairs of
             // V <- V J.  All LDS reads are issued before any arithmetic so that one latency is exposed, not three.
-            if constexpr (2 * HP * HP <= 256 && 2 * S * HP <= 512) {
+            if constexpr (L::kTables) {
                 // item (m, P, Q): the 2x2 block (pair P, pair Q) of K_m and the eigenvector entries of rows Q and Q + HP in
                 // the two columns of pair P -- both need the rotation of pair P, so an item reads two rotations, not four
                 const bool hasB = tid < nm * HP * HP;
@@ -857,7 +872,7 @@ __device__ void weights_nd(double* __restrict__ Sm) {
     // -- eigenvalues and tensor-product weights (quadratures.py:165-170)
     double* lam = Sm + L::oLam;
     double* W = Sm + L::oW;
-    for (int e = tid; e < 2 * S; e += nthr) lam[(e / S) * NP + (e % S)] = K[(e / S) * NP * LD + (e % S) * (LD + 1)];
+    for (int e = tid; e < 2 * S; e += nthr) lam[(e / S) * L::LS + (e % S)] = K[(e / S) * NP * LD + (e % S) * (LD + 1)];
     const double* V0 = V;
     const double* V1 = V + NP * LD;
     for (int e = tid; e < S * S; e += nthr) {
@@ -1147,6 +1162,86 @@ __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const 
     }
 }
 
+// Chebyshev-grid form of the rule for a Normal-closure prediction.  The integrand E[(X' - c)^n | x] is a polynomial in x whose
+// degree per variable is at most g (2N - 1), g = max(deg mu, ceil(deg Sigma / 2)) (each step of the Stein recursion
+// multiplies by mu - c, every second one by an entry of Sigma).  A polynomial of degree < NCP per variable equals its
+// interpolant on the NCP x NCP Chebyshev grid of a box that contains the spectra, so the rule's bilinear form (*) of it is
+//     sum_pq Omega_pq F(x_p, x_q),     Omega_pq = (l_p(X_0) e_0)^T (l_q(X_1) e_0),   l_p the cardinal polynomials of the grid,
+// EXACTLY the reference's sum over its s^2 eigen-nodes (quadratures.py:165-170) in exact arithmetic -- with no
+// eigen-decomposition: l_p(X_k) e_0 = sum_a D[a][p] T_a(Khat_k) e_0 from NCP - 1 matrix-vector products per matrix.
+// Leaves the grid coordinates (in units of lambda) in lam[k][p] and Omega in W[p][q]; waves 0 and 1 work, then all.
+template <int N, int TK>
+__device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
+    using L = NdTile<N, TK>;
+    constexpr int S = L::S, NP = L::NP, LD = L::LD, LS = L::LS, NCM = L::kNcpMax;
+    const int tid = threadIdx.x;
+    double* U = Sm + L::oU;              // [2][ncp][NP]
+    const double* Dt = Sm + L::oChD;     // [a][p], row stride ncp
+    if (tid < 128) {
+        const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
+        const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
+        double* Uw = U + w * ncp * NP;
+        double kr[S];
+        static_for<0, S>([&](auto Jc) { kr[Jc] = Kw[Jc]; });
+        // Gershgorin interval of K_w
+        double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+        static_for<0, S>([&](auto Jc) {
+            if constexpr (Jc % 3 == 0) r0 += fabs(kr[Jc]); else if constexpr (Jc % 3 == 1) r1 += fabs(kr[Jc]); else r2 += fabs(kr[Jc]);
+        });
+        const double dg = Kw[li];
+        const double rad = ((r0 + r1) + r2) - fabs(dg);
+        const double lo = (lane < S) ? dg - rad : 1.79e308, hi = (lane < S) ? dg + rad : -1.79e308;
+        const double dmin = -wave_max64(-lo), dmax = wave_max64(hi);
+        const double mid = 0.5 * (dmin + dmax);
+        double half = 0.5 * (dmax - dmin);
+        half = (half > 0.0) ? half : 1.0;
+        const double ihalf = rcp_nr(half);
+        // T_a(Khat) e_0, Khat u = (K u - mid u) / half
+        double tprev = (li == 0) ? 1.0 : 0.0;
+        double tcur = (kr[0] - ((li == 0) ? mid : 0.0)) * ihalf;
+        if (lane < S) { Uw[lane] = tprev; Uw[NP + lane] = tcur; }
+        for (int a = 2; a < ncp; ++a) {
+            const double ku = fma(-mid, tcur, dpp_matvec<S>(kr, tcur)) * ihalf;
+            const double tnext = fma(2.0, ku, -tprev);
+            if (lane < S) Uw[a * NP + lane] = tnext;
+            tprev = tcur; tcur = tnext;
+        }
+        wave_sync();
+        // cardinal vectors: u_p[r] = sum_a D[a][p] t_a[r], this lane's component r, in place
+        double ta[NCM];
+        static_for<0, NCM>([&](auto Ac) { ta[Ac] = (Ac < ncp) ? Uw[((Ac < ncp) ? (int)Ac : 0) * NP + li] : 0.0; });
+        wave_sync();
+        for (int p = 0; p < ncp; ++p) {
+            double a0 = 0.0, a1 = 0.0;
+            static_for<0, NCM>([&](auto Ac) {      // (rows a >= ncp of the table are zero)
+                const double dv = Dt[((Ac < ncp) ? (int)Ac : 0) * ncp + p];
+                const double tv = ta[Ac];
+                if constexpr (Ac % 2 == 0) a0 = fma(dv, tv, a0); else a1 = fma(dv, tv, a1);
+            });
+            if (lane < S) Uw[p * NP + lane] = a0 + a1;
+        }
+        if (lane < ncp) Sm[L::oLam + w * LS + lane] = fma(half, Sm[L::oChG + lane], mid);
+    }
+    __syncthreads();
+    double* W = Sm + L::oW;
+    const double* U0 = U;
+    const double* U1 = U + ncp * NP;
+    for (int e = tid; e < ncp * ncp; e += 256) {
+        const int pp = e / ncp, q = e - pp * ncp;
+        const double* u = U0 + pp * NP;
+        const double* v = U1 + q * NP;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        static_for<0, S>([&](auto Jc) {
+            constexpr int j = Jc;
+            if constexpr (j % 3 == 0) a0 = fma(u[j], v[j], a0);
+            else if constexpr (j % 3 == 1) a1 = fma(u[j], v[j], a1);
+            else a2 = fma(u[j], v[j], a2);
+        });
+        W[e] = (a0 + a1) + a2;
+    }
+    __syncthreads();
+}
+
 // TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
 template <int N, int TK>
 __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) {
@@ -1238,6 +1333,26 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
     int lik_mask = 0;
     for (int f = 0; f < a.n_factors; ++f) lik_mask |= 1 << a.fac_comp[f];
     const int ubeg = (lik_mask & 1) ? 0 : 1, uend = (lik_mask & 2) ? 2 : 1;
+    // Normal closure: the size of the Chebyshev grid that integrates every moment's integrand exactly (cheb_grid_rule_nd), from
+    // the per-variable degrees of mu (rows 0, 1) and Sigma (rows 2 .. 4); 0 = too large for the tables, eigen-nodes instead
+    int ncp = 0;
+    if constexpr (TK == 1) {
+        int dmu = 0, dsg = 0;
+        for (int r = 0; r < 5; ++r) {
+            const int ex = a.ext[r], dg = max(ex & 0xff, ex >> 8) - 1;
+            if (r < 2) dmu = max(dmu, dg); else dsg = max(dsg, dg);
+        }
+        const int g = max(1, max(dmu, (dsg + 1) / 2));
+        ncp = g * (P - 1) + 1;
+        if (ncp > L::kNcpMax || a.force_eigen) ncp = 0;
+        if (ncp > 0) {
+            for (int e = tid; e < ncp * ncp; e += 256) {
+                const int aa = e / ncp, pp = e - aa * ncp;
+                Sm[L::oChD + e] = ((aa == 0) ? 1.0 : 2.0) / (double)ncp * cospi((double)aa * ((double)pp + 0.5) / (double)ncp);
+            }
+            if (tid < ncp) Sm[L::oChG + tid] = cospi(((double)tid + 0.5) / (double)ncp);
+        }
+    }
     __syncthreads();
     bool dead = resume ? (cw[Z + 6] != 0.0) : false;
     int warm_mask = resume ? (int)cw[Z + 7] : 0;
@@ -1405,18 +1520,27 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                 } else {
                     // ---- Normal closure: the s^2 nodes explicitly.  Both K_k diagonalised, weights, then per node the
                     //      Stein recursion (equal to raw_moments_mvn_kan(mu(x) - c, S(x), (a, b)), moments.py:110-154)
-                    jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
-                    weights_nd<N, TK>(Sm);
-                    warm_mask = poisoned ? 0 : 3;
+                    //      -- or, when the degree of the integrands allows, the Chebyshev grid with the weights of the same
+                    //      bilinear form (cheb_grid_rule_nd: no eigen-decomposition)
+                    int Rn = R, Sn = S;
+                    if (ncp > 0) {
+                        cheb_grid_rule_nd<N, TK>(Sm, ncp);
+                        Rn = ncp * ncp; Sn = ncp;
+                    } else {
+                        jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
+                        weights_nd<N, TK>(Sm);
+                        warm_mask = poisoned ? 0 : 3;
+                    }
                     ND_STAMP_BEGIN;
+                    constexpr int LS = L::LS;
                     const double* lam = Sm + L::oLam;
                     const double* W = Sm + L::oW;
                     const double qm0 = mean0, qm1 = mean1, qs0 = scale0, qs1 = scale1;
                     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                    for (int e = tid; e < R; e += 256) {
-                        const int i0 = e / S, i1 = e - i0 * S;
+                    for (int e = tid; e < Rn; e += 256) {
+                        const int i0 = e / Sn, i1 = e - i0 * Sn;
                         const double w = W[e];
-                        const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[NP + i1], qs1, qm1);
+                        const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[LS + i1], qs1, qm1);
                         s0 = fma(w, poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s0);       // mu_0(x)
                         s1 = fma(w, poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s1);       // mu_1(x)
                         if (scaled) {  // scale <- sqrt(sum w var_k(x)), filtering.py:186
@@ -1447,14 +1571,14 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     //   M(0,b) = m_1 M(0,b-1) + (b-1) S_11 M(0,b-2)
                     //   M(a,b) = m_0 M(a-1,b) + (a-1) S_00 M(a-2,b) + b S_01 M(a-1,b-1)
                     // three rows of the table live at a time; entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b
-                    for (int base = 0; base < R; base += 256) {
+                    for (int base = 0; base < Rn; base += 256) {
                         double wA, mA0, mA1, sA00, sA01, sA11;
                         {
                             const int eA = base + tid;
-                            const bool okA = eA < R;
-                            const int iA0 = okA ? eA / S : 0, iA1 = okA ? eA - iA0 * S : 0;
+                            const bool okA = eA < Rn;
+                            const int iA0 = okA ? eA / Sn : 0, iA1 = okA ? eA - iA0 * Sn : 0;
                             wA = okA ? W[eA] : 0.0;
-                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[NP + iA1], qs1, qm1);
+                            const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[LS + iA1], qs1, qm1);
                             mA0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xA0, xA1) - c0;
                             mA1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xA0, xA1) - c1;
                             sA00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xA0, xA1);
