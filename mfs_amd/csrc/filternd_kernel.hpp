@@ -1206,26 +1206,35 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
             if (lane < S) Uw[a * NP + lane] = tnext;
             tprev = tcur; tcur = tnext;
         }
-        wave_sync();
-        // cardinal vectors: u_p[r] = sum_a D[a][p] t_a[r], this lane's component r, in place
-        double ta[NCM];
-        static_for<0, NCM>([&](auto Ac) { ta[Ac] = (Ac < ncp) ? Uw[((Ac < ncp) ? (int)Ac : 0) * NP + li] : 0.0; });
-        wave_sync();
-        for (int p = 0; p < ncp; ++p) {
-            double a0 = 0.0, a1 = 0.0;
-            static_for<0, NCM>([&](auto Ac) {      // (rows a >= ncp of the table are zero)
-                const double dv = Dt[((Ac < ncp) ? (int)Ac : 0) * ncp + p];
-                const double tv = ta[Ac];
-                if constexpr (Ac % 2 == 0) a0 = fma(dv, tv, a0); else a1 = fma(dv, tv, a1);
-            });
-            if (lane < S) Uw[p * NP + lane] = a0 + a1;
-        }
         if (lane < ncp) Sm[L::oLam + w * LS + lane] = fma(half, Sm[L::oChG + lane], mid);
     }
     __syncthreads();
+    // cardinal vectors u_p = sum_a D[a][p] t_a on all threads, into the tiles of G, K_0, K_1, V_0, V_1 (the matrices have done
+    // their work for this half-step; the caller drops the warm start of a later Jacobi fallback)
+    double* Uo = Sm + L::oA;             // [2][ncp][NP]
+    for (int e = tid; e < 2 * ncp * S; e += 256) {
+        const int w = e / (ncp * S), f = e - w * ncp * S, pp = f / S, r = f - pp * S;
+        const double* tw = U + w * ncp * NP + r;
+        // fixed trip count, every LDS read issued before the arithmetic (terms a >= ncp masked by a select)
+        double dv[NCM], tv[NCM];
+        static_for<0, NCM>([&](auto Ac) {
+            const int ai = (Ac < ncp) ? (int)Ac : 0;
+            dv[Ac] = Dt[ai * ncp + pp];
+            tv[Ac] = tw[ai * NP];
+        });
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        static_for<0, NCM>([&](auto Ac) {
+            const double t = (Ac < ncp) ? tv[Ac] : 0.0;
+            if constexpr (Ac % 3 == 0) a0 = fma(dv[Ac], t, a0);
+            else if constexpr (Ac % 3 == 1) a1 = fma(dv[Ac], t, a1);
+            else a2 = fma(dv[Ac], t, a2);
+        });
+        Uo[(w * ncp + pp) * NP + r] = (a0 + a1) + a2;
+    }
+    __syncthreads();
     double* W = Sm + L::oW;
-    const double* U0 = U;
-    const double* U1 = U + ncp * NP;
+    const double* U0 = Uo;
+    const double* U1 = Uo + ncp * NP;
     for (int e = tid; e < ncp * ncp; e += 256) {
         const int pp = e / ncp, q = e - pp * ncp;
         const double* u = U0 + pp * NP;
@@ -1344,7 +1353,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         }
         const int g = max(1, max(dmu, (dsg + 1) / 2));
         ncp = g * (P - 1) + 1;
-        if (ncp > L::kNcpMax || a.force_eigen) ncp = 0;
+        if (ncp > L::kNcpMax || 2 * ncp > 5 * LD || a.force_eigen) ncp = 0;   // (table size; the cardinal vectors' room)
         if (ncp > 0) {
             for (int e = tid; e < ncp * ncp; e += 256) {
                 const int aa = e / ncp, pp = e - aa * ncp;
@@ -1524,8 +1533,11 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                     //      bilinear form (cheb_grid_rule_nd: no eigen-decomposition)
                     int Rn = R, Sn = S;
                     if (ncp > 0) {
+                        ND_STAMP_BEGIN;
                         cheb_grid_rule_nd<N, TK>(Sm, ncp);
                         Rn = ncp * ncp; Sn = ncp;
+                        warm_mask = 0;        // (the eigenvector tiles were scratch)
+                        ND_STAMP(3);
                     } else {
                         jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
                         weights_nd<N, TK>(Sm);

@@ -28,7 +28,7 @@ int run(int argc, char** argv) {
     hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(B), dim3(256), lds, 0, a);
     hipDeviceSynchronize();
     unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
-    const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
+    const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls / Chebyshev-grid rule", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
     double tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
     printf("steps %llu, Jacobi sweeps %llu (%.2f per update rule; one matrix)\n", st[9], st[8], (double)st[8] / st[9]);
     for (int i = 0; i < 8; ++i) printf("%-24s %10.0f cycles per step  %5.1f %%\n", names[i], (double)st[i] / st[9], 100.0 * st[i] / tot);
