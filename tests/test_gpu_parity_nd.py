@@ -108,7 +108,7 @@ def test_prey_predator_normal_closures(N, T, order):
     rc = omd.moment_filter_nd_cms((ocms, 'index'), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
     npt.assert_allclose(nell[0], rc[2], rtol=1e-6)
     npt.assert_allclose(means[0], rc[1], rtol=1e-6)
-    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
+    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6)
     if N <= 3:
         rmss, nell_r = filtering.moment_filter_nd_rms((fns[0], 'index'), pmf, ys, (mi, inds), gs.rms)
         rr = omd.moment_filter_nd_rms((orms, 'index'), opmf, ys[0], (mi, inds), ogs.rms)
@@ -152,13 +152,13 @@ def test_prey_predator_scaled_mode(N, T, family):
     cmss, means_c, nell_c = filtering.moment_filter_nd_cms((fns[1], sig), fns[3], pmf, ys, (mi, inds), gs.cms, gs.mean)
     npt.assert_allclose(means, means_c, rtol=1e-7 if N <= 4 else 1e-5)
     npt.assert_allclose(nell, nell_c, rtol=1e-7 if N <= 4 else 1e-5)
-    npt.assert_allclose(scales ** 2, np.stack([cmss[:, :, 5], cmss[:, :, 3]], axis=-1), rtol=1e-6 if N <= 4 else 1e-4)
+    npt.assert_allclose(scales ** 2, np.stack([cmss[:, :, 5], cmss[:, :, 3]], axis=-1), rtol=1e-6)
     npt.assert_allclose(scmss[:, :, 5], 1., rtol=1e-9)           # posterior scaled second moments are 1 by construction
     rs = omd.moment_filter_nd_scms((oscms, sig), omean_var, opmf, ys[0], (mi, inds), scms0, ogs.mean, scale0)
     npt.assert_allclose(nell[0], rs[3], rtol=1e-6)
     npt.assert_allclose(means[0], rs[1], rtol=1e-6)
     npt.assert_allclose(scales[0], rs[2], rtol=1e-6)
-    _assert_moments(scmss[0], rs[0], mi, rtol=1e-6 if N <= 4 else 1e-4)
+    _assert_moments(scmss[0], rs[0], mi, rtol=1e-6)
     with pytest.raises(sym.NotDeviceDescribable):   # the mean-only closure is not the mean-and-variance closure
         filtering.moment_filter_nd_scms((fns[2], sig), fns[3], pmf, ys, (mi, inds), scms0, gs.mean, scale0)
 
@@ -241,7 +241,7 @@ def test_maximum_order_N7(family):
     rc = omd.moment_filter_nd_cms((ocms, sig), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
     npt.assert_allclose(nell[0], rc[2], rtol=1e-6)
     npt.assert_allclose(means[0], rc[1], rtol=1e-6)
-    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6 if family == 'tme_2' else 1e-4)
+    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6)
 
 
 def test_nd_empty_batch_and_zero_steps():
