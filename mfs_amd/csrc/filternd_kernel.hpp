@@ -123,7 +123,7 @@ struct NdTile {
     static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
     // Normal closures integrate over s^2 eigen-nodes (weights W, coordinates lam) or -- when the integrand's degree allows --
     // over an NCP x NCP Chebyshev grid with the weights Omega of the same bilinear form (kNcpMax bounds NCP)
-    static constexpr int kNcpMax = 24;
+    static constexpr int kNcpMax = 28;
     static constexpr int LS = (NP > kNcpMax) ? NP : kNcpMax;           // stride of the two coordinate lists
     static constexpr int nWt = (R > kNcpMax * kNcpMax) ? R : kNcpMax * kNcpMax;
     static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] / [NCP][NCP] node weights (Normal closures)
@@ -174,7 +174,7 @@ struct NdTile {
     // per-rule gather then makes no global-memory round trip
     static constexpr int oGi = oFf + (kOperator ? P * FFS : 0);
     static constexpr int nGi = (3 * S * S + 3) / 4;
-    static constexpr int nChebGrid = (TK == 1) ? 24 * 24 + 24 : 0;       // (kNcpMax^2 + kNcpMax, laid out after the gather table)
+    static constexpr int nChebGrid = (TK == 1) ? 28 * 28 + 28 : 0;       // (kNcpMax^2 + kNcpMax, laid out after the gather table)
     static constexpr bool kGatherLds = (oGi + nGi + nChebGrid) * 8 <= 80 * 1024;
     static constexpr int kDoubles0 = oGi + (kGatherLds ? nGi : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
