@@ -21,9 +21,11 @@
 //            tests/test_filtering.py:44-46): h_k = lik_k(X_k) e_0 needs the eigen-decomposition of K_k for the
 //            components a factor reads ONLY (cyclic Jacobi, warm-started from the previous update rule); posterior
 //            moments are M[p][q] = (K_0^p h_0)^T (K_1^q h_1) / p_y shifted to the posterior mean.
-//   predict (Normal closures, moments.py:257-411)  E[(X' - c)^n | x] is a polynomial of degree ~ |n| deg(mu) in x:
-//            here the s^2 nodes are formed explicitly (both K_k diagonalised, weights as above) and the Stein recursion
-//            runs per node, 16 moments at a time through a transposing DPP row reduction.
+//   predict (Normal closures, moments.py:257-411)  E[(X' - c)^n | x] is a polynomial of degree ~ |n| deg(mu) in x, not
+//            separable: it is integrated on an NCP x NCP Chebyshev grid with the weights Omega_pq = (l_p(X_0) e_0)^T (l_q(X_1) e_0)
+//            of the same bilinear form (cheb_grid_rule_nd) -- exact, because NCP exceeds the integrands' degree per variable --
+//            and the Stein recursion runs per grid point, 16 moments at a time through a transposing DPP row reduction.  Only
+//            when NCP would not fit its table are the reference's s^2 eigen-nodes formed (both K_k diagonalised by cyclic Jacobi).
 // Front end of every rule: G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; Cholesky and both
 // triangular solves on one wave in registers (columns of L reach the other lanes as DPP operands after a lane-swap
 // duplication).  No MFMA: s <= 28, fp64, sequential.
