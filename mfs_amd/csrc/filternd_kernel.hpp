@@ -13,14 +13,16 @@
 // the bilinear form of two matrix functions of K_k = R^-1 H_k R^-T applied to the first unit vector.  Every sum the
 // filter takes is a sum of such terms:
 //   predict (operator tables, moments.py:414-479)  the integrand sum_kappa Q_kappa(x) d^kappa (x - c)^n is a polynomial:
-//            (*) needs only the Krylov vectors K_k^p e_0 and NO eigen-decomposition; the moments are a contraction of
-//            the re-centred coefficient blocks with the array M[p][q] = (K_0^p e_0)^T (K_1^q e_0), binomially shifted
-//            to the new mean.  Same numbers as the node sums (1e-10 in an fp64 side-by-side over 150 steps), ~2 % of
-//            their flops, and the d eigensolves of quadratures.py:163 disappear from this half-step.
+//            (*) needs only Krylov vectors and NO eigen-decomposition -- a few powers K_k^p e_0 for the low corner of the rule's
+//            moment array (the new means), then (K_k - d_k I)^p e_0 with the matrices shifted to the NEW mean, whose array
+//            M[p][q] = ((K_0 - d_0)^p e_0)^T ((K_1 - d_1)^q e_0) is contracted with the coefficient blocks re-centred there.
+//            Same numbers as the node sums (1e-10 in an fp64 side-by-side over 150 steps), ~2 % of their flops, and the
+//            d eigensolves of quadratures.py:163 disappear from this half-step.
 //   update   the likelihood is a product of factors, each a function of ONE state component (ss_models.py:63-67,
-//            tests/test_filtering.py:44-46): h_k = lik_k(X_k) e_0 needs the eigen-decomposition of K_k for the
-//            components a factor reads ONLY (cyclic Jacobi, warm-started from the previous update rule); posterior
-//            moments are M[p][q] = (K_0^p h_0)^T (K_1^q h_1) / p_y shifted to the posterior mean.
+//            tests/test_filtering.py:44-46): h_k = lik_k(X_k) e_0 by a CHECKED Chebyshev interpolant of the factor on the
+//            spectrum's interval (cheb_h_nd; cyclic Jacobi + spectral evaluation only when the check fails); p_y and the
+//            posterior mean from h_k and K_k h_k; posterior moments M[p][q] = ((K_0 - d_0)^p h_0)^T ((K_1 - d_1)^q h_1) / p_y
+//            with the matrices shifted to the posterior mean.
 //   predict (Normal closures, moments.py:257-411)  E[(X' - c)^n | x] is a polynomial of degree ~ |n| deg(mu) in x, not
 //            separable: it is integrated on an NCP x NCP Chebyshev grid with the weights Omega_pq = (l_p(X_0) e_0)^T (l_q(X_1) e_0)
 //            of the same bilinear form (cheb_grid_rule_nd) -- exact, because NCP exceeds the integrands' degree per variable --
