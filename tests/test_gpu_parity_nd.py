@@ -89,7 +89,10 @@ def test_nd_shapes_errors_and_single_trajectory():
     assert fn[1] == -1 and nell[1] == nellB[1]
 
 
-@pytest.mark.parametrize('N,T,order', [(2, 60, 2), (3, 40, 2), (3, 40, 'euler'), (4, 25, 3), (5, 10, 2)])
+# (grid sizes of the Chebyshev-grid prediction, NCP = g (2N - 1) + 1: 7, 11, 6, 22, 19, 12, 28 -- and 34 > 28 at N = 6 with
+#  TME-normal-3, which takes the eigen-node route)
+@pytest.mark.parametrize('N,T,order', [(2, 60, 2), (3, 40, 2), (3, 40, 'euler'), (4, 25, 3), (5, 10, 2), (6, 8, 'euler'), (5, 6, 3),
+                                       (6, 5, 3)])
 def test_prey_predator_normal_closures(N, T, order):
     """'index'-signature Normal closures (mfs/multi_dims/moments.py:257-411; used by dardel/prey_predator/mf.py with
     --trans=tme_normal_2 / euler; reference tests/test_filtering.py:182-222) against the oracle's Kan-formula path."""
@@ -108,7 +111,7 @@ def test_prey_predator_normal_closures(N, T, order):
     rc = omd.moment_filter_nd_cms((ocms, 'index'), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)
     npt.assert_allclose(nell[0], rc[2], rtol=1e-6)
     npt.assert_allclose(means[0], rc[1], rtol=1e-6)
-    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6)
+    _assert_moments(cmss[0], rc[0], mi, rtol=1e-6 if not (N == 6 and order == 3) else 1e-4)   # (eigen-node route: Jacobi rounding in the weights)
     if N <= 3:
         rmss, nell_r = filtering.moment_filter_nd_rms((fns[0], 'index'), pmf, ys, (mi, inds), gs.rms)
         rr = omd.moment_filter_nd_rms((orms, 'index'), opmf, ys[0], (mi, inds), ogs.rms)
