@@ -257,3 +257,21 @@ def test_nd_empty_batch_and_zero_steps():
     m, means, nell = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, ys[:, :0], (mi, inds), gs.cms, gs.mean)
     assert m.shape == (3, 0, mi.shape[0]) and means.shape == (3, 0, 2)
     npt.assert_array_equal(nell, np.zeros(3))
+
+
+def test_normal_closure_poisoning_is_per_replicate():
+    """An indefinite start (negative variance) NaN-poisons that replicate at step 0 on the Normal-closure path too (its
+    prediction runs on the Chebyshev grid: the rule's matrices are NaN, so are the grid weights), the neighbour is untouched."""
+    N = 4
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, pmf, _ = ss_models.prey_predator(mi)
+    fns = moments.sde_cond_moments_tme_normal(drift, disp, dt, 2, mi)
+    ys, _ = synth.prey_predator_batch(2, 20, dt, seed=1)
+    cms0 = np.tile(gs.cms, (2, 1))
+    cms0[0, 5] = -1.
+    m, means, nell, fn = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pmf, ys, (mi, inds), cms0,
+                                                        np.tile(gs.mean, (2, 1)), return_first_nan=True)
+    assert list(fn) == [0, -1] and np.isnan(nell[0]) and np.all(np.isnan(m[0])) and np.all(np.isfinite(m[1]))
+    alone = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pmf, ys[1], (mi, inds), gs.cms, gs.mean)
+    npt.assert_array_equal(m[1], alone[0])
