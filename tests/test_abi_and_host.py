@@ -184,3 +184,22 @@ def test_odd_moment_count_warns_like_the_reference():
         ys2, squeeze, B, T, ms0, N, batched, mean0, scale0 = filtering._prep_inputs(ic.rms[:5], None, None, np.zeros(4),
                                                                                     tables, lik)
     assert N == 2 and ms0.shape == (5,) and squeeze and (B, T) == (1, 4)
+
+
+def test_header_constants_match_the_python_mirror():
+    """The numeric #defines a binding needs (modes, table layouts, limits) have the same values in include/mfs_hip.h and in
+    mfs_amd/_lib.py, and mfs_model_nd has the layout the header describes."""
+    text = open(os.path.join(ROOT, 'include', 'mfs_hip.h')).read()
+    defs = {k: v for k, v in re.findall(r'^#define\s+(MFS_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b', text, flags=re.M)}
+    val = lambda name: int(defs[name], 0)   # noqa: E731
+    assert val('MFS_ABI_VERSION') == _lib.ABI_VERSION
+    assert val('MFS_MODE_ODD_TAIL') == _lib.MODE_ODD_TAIL
+    assert (val('MFS_ND_TERMS'), val('MFS_ND_ROWS'), val('MFS_ND_TERMS_MAX'), val('MFS_ND_ROWS_MAX')) == \
+           (_lib.ND_TERMS, _lib.ND_ROWS, _lib.ND_TERMS_MAX, _lib.ND_ROWS_MAX)
+    assert (val('MFS_ND_MAX_EXTENT'), val('MFS_ND_MAX_EXTENT_HI'), val('MFS_ND_MAX_FACTORS')) == \
+           (_lib.ND_MAX_EXTENT, _lib.ND_MAX_EXTENT_HI, _lib.ND_MAX_FACTORS)
+    assert (val('MFS_ND_TRANS_OPERATOR'), val('MFS_ND_TRANS_GAUSSIAN')) == (_lib.ND_TRANS_OPERATOR, _lib.ND_TRANS_GAUSSIAN)
+    assert _lib.nd_table_rows(_lib.ND_TERMS) == _lib.ND_ROWS and _lib.nd_table_rows(_lib.ND_TERMS + 1) == _lib.ND_ROWS_MAX
+    assert len(_lib.ND_KAPPAS) == _lib.ND_TERMS_MAX and _lib.ND_KAPPAS[:_lib.ND_TERMS] == [(a, s - a) for s in range(1, 5) for a in range(s + 1)]
+    # mfs_model_nd: 6 ints, 4 int[2] arrays, 2 ints, 2 pointers
+    assert C.sizeof(_lib.MfsModelNd) == (6 + 8 + 2) * 4 + 2 * 8
