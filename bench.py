@@ -2,8 +2,14 @@
 """bench.py -- filter time-steps/s of the moment-filter hot path on N MI355X GPUs (one process per GPU).
 
     python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (self-launching: the parent starts one child per GPU, below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the process is a LAUNCHER: it never touches the GPU (no library
+load, no device count), starts N copies of itself with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set
+(subprocess.Popen -- never an exec from a process that has initialised the GPU), relays rank 0's JSON line and exits with
+the worst child status.
 
 Workload (BASELINE.json configs[1]): Benes--Bernoulli 1-D, N = 15, T = 1000, B = 4096 replicates PER GPU (weak
 scaling: replicates are independent, sharded with no data-path collective; the per-replicate NLL vector is
@@ -94,6 +100,9 @@ def parse_args():
     p.add_argument('--no-other-workloads', action='store_true', help='skip the short runs of configs 3 / 4 / 5')
     p.add_argument('--allow-host-gather', action='store_true',
                    help='multi-rank: exit 0 even if the NLL all-gather fell back from RCCL to the host route')
+    p.add_argument('--dry-run', action='store_true',
+                   help='rendezvous, communicator set-up and the JSON line only: no workload, no kernel (launcher rehearsal)')
+    p.add_argument('--launch-timeout', type=float, default=1500., help='self-launched runs: seconds before the children are stopped')
     return p.parse_args()
 
 
@@ -417,23 +426,97 @@ def summarise(w, res, steps, world, want_moments, live_total=None):
             'hbm_gbs': algo / (kern_ms * 1e-3) / 1e9}
 
 
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: one child process per GPU, this process only supervises.  It must not
+    initialise the GPU (the children own the devices, and a process that has touched the GPU must never exec), so nothing
+    of mfs_amd is imported here."""
+    import socket
+    import subprocess
+    import threading
+    n = args.gpus
+    with socket.socket() as sock:            # a free rendezvous port on the loopback interface
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+
+    def relay():                             # rank 0 prints the one JSON line; library chatter (RCCL writes its
+        for raw in procs[0].stdout:          # warnings to stdout) goes to stderr so that stdout stays one line
+            line = raw.decode(errors='replace')
+            out = sys.stdout if line.lstrip().startswith('{"metric"') else sys.stderr
+            out.write(line)
+            out.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    deadline = time.time() + args.launch_timeout
+    grace = None                             # once a rank has failed the others get a minute to notice and leave
+    while any(p.poll() is None for p in procs):
+        now = time.time()
+        if grace is None and any(p.poll() not in (None, 0) for p in procs):
+            grace = now + 60.
+        if now > deadline or (grace is not None and now > grace):
+            for p in procs:                  # exactly the processes started above
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    th.join(10.)
+    worst = 0
+    for c in codes:
+        c = 128 - c if c < 0 else c          # killed by a signal
+        worst = max(worst, c)
+    if worst:
+        print(f'bench.py launcher: child exit statuses {codes}', file=sys.stderr)
+    return worst
+
+
+def dry_run(args, comm, rank, world):
+    """--dry-run: everything up to the communicator (rendezvous, RCCL initialisation or its reported failure), then the line."""
+    exit_code = comm.exit_status(True, args.allow_host_gather)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'filter time-steps/sec', 'value': None, 'unit': 'filter-steps/s', 'n_gpus': world, 'dry_run': True,
+            'steps': args.steps, 'warmup': args.warmup, 'config': {'workload': args.workload},
+            'nll_allgather_ok': not comm.degraded,
+            'nll_allgather': ('rccl ncclAllGather' if comm.data == 'rccl' and world > 1 else
+                              'single rank' if world == 1 else f'FAILED: {comm.rccl_error}')}), flush=True)
+    comm.close(exit_code)
+    sys.exit(exit_code)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))         # launcher: nothing below runs in this process
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N bench.py')
         args.gpus = world
 
     from mfs_amd import _lib, dist
     L = _lib.lib()
     # one GPU per rank; on a box with fewer GPUs than ranks (rehearsals only) ranks share devices and RCCL, which
     # refuses duplicate GPUs, fails: reported, and the exit status says so
-    device = local_rank % max(_lib.device_count(), 1)
+    try:
+        n_dev = _lib.device_count()
+    except _lib.MfsError:
+        if not args.dry_run:                 # no device, no measurement: fail loudly
+            raise
+        n_dev = 0                            # launcher rehearsal on a box without a GPU
+    device = local_rank % max(n_dev, 1)
     comm = dist.Communicator.from_env(device=device)  # TCP control plane (mfs_amd/rdzv.py) + RCCL for the NLL gather
+    if args.dry_run:
+        dry_run(args, comm, rank, world)
     _lib.check(L.mfs_set_device(device))
     want_moments = not args.no_moments
 
@@ -501,7 +584,7 @@ def main():
     else:
         w.release()
     exit_code = comm.exit_status(gather_ok, args.allow_host_gather)
-    comm.close()
+    comm.close(exit_code)
     sys.exit(exit_code)
 
 

@@ -175,14 +175,21 @@ class Communicator:
         local = np.ascontiguousarray(local, dtype=np.float64)
         return np.concatenate(self._allgather_obj(local))
 
-    def close(self):
+    def close(self, status: int = None):
+        """`status`: the exit status the caller is about to leave with (`exit_status(...)`); only the abandoned-init path
+        uses it, because that path cannot return to the caller."""
         if self._abandoned:
             # the interpreter's shutdown would wait on (or tear down under) the stuck RCCL call: results are out, leave
             import sys
-            self.barrier()
+            try:
+                if self._rdzv is not None:
+                    self._rdzv.set_timeout(10.)     # a peer that is stuck or gone must not hold this rank for minutes
+                self.barrier()
+            except Exception:   # noqa: BLE001 -- leaving anyway
+                pass
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(EXIT_RCCL_FAILED)
+            os._exit(EXIT_RCCL_FAILED if status is None else status)
         if self._comm is not None:
             _lib.lib().mfs_comm_destroy(self._comm)
             self._comm = None

@@ -37,7 +37,9 @@ def _enc(obj):
     if isinstance(obj, (bytes, bytearray)):
         return {'b': base64.b64encode(bytes(obj)).decode('ascii')}
     if isinstance(obj, np.ndarray):
-        a = np.ascontiguousarray(obj, dtype=np.float64)
+        if obj.dtype != np.float64:      # no silent conversion: an int64 index vector would come back as floats
+            raise TypeError(f'the rendezvous control plane carries float64 vectors only, not {obj.dtype}')
+        a = np.ascontiguousarray(obj)
         return {'a': base64.b64encode(a.tobytes()).decode('ascii'), 's': list(a.shape)}
     if isinstance(obj, (list, tuple)):
         return {'t' if isinstance(obj, tuple) else 'l': [_enc(v) for v in obj]}
@@ -75,9 +77,9 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
-def _recv(sock):
+def _recv(sock, limit=_MAX_MESSAGE):
     n = struct.unpack('<Q', _recv_exact(sock, 8))[0]
-    if n > _MAX_MESSAGE:
+    if n > limit:
         raise ConnectionError(f'rendezvous message of {n} bytes refused')
     return _dec(json.loads(_recv_exact(sock, n).decode('utf-8')))
 
@@ -178,7 +180,14 @@ class TcpRendezvous:
                 _send(p, objs)
             return objs
         _send(self._sock, obj)
-        return _recv(self._sock)
+        return _recv(self._sock, _MAX_MESSAGE * self.world)     # the reply is the concatenation of every rank's part
+
+    def set_timeout(self, seconds: float):
+        """Socket timeout of every later collective (a rank leaving after a failure must not wait for the full one)."""
+        for p in self._peers:
+            p.settimeout(seconds)
+        if self._sock is not None:
+            self._sock.settimeout(seconds)
 
     def barrier(self):
         self.allgather(None)

@@ -139,7 +139,8 @@ def moment_quadrature(ms, mean=0, scale=1):
 def benes_bernoulli_cms(cms0, mean0, ys, dt=1e-2, tme_order=3, slope=5., dps=80, scaled=False, scale0=None):
     """Central-moment (or scaled-central) Benes--Bernoulli filter in `dps`-digit arithmetic.
 
-    Returns dict(moments (T, 2N) as lists of mpf, means, scales, nell, first_nan).  After a poisoning event every
+    Returns dict(moments (T, 2N) as lists of mpf, means, scales, nell, first_nan, nell_cum = the running NLL after
+    each step).  After a poisoning event every
     later entry is None.
     """
     mp.mp.dps = dps
@@ -152,17 +153,17 @@ def benes_bernoulli_cms(cms0, mean0, ys, dt=1e-2, tme_order=3, slope=5., dps=80,
     scale = mp.mpf(float(scale0)) if scaled else mp.mpf(1)
     slope = mp.mpf(float(slope))
     ff = [[mp.mpf(math.perm(n, k)) if k <= n else mp.mpf(0) for k in range(len(Q) + 1)] for n in range(M2)]
-    out_m, out_mean, out_scale = [], [], []
+    out_m, out_mean, out_scale, out_nell = [], [], [], []
     nell = mp.mpf(0)
     first_nan = -1
     for t, y in enumerate(ys):
         if first_nan >= 0:
-            out_m.append(None); out_mean.append(None); out_scale.append(None)
+            out_m.append(None); out_mean.append(None); out_scale.append(None); out_nell.append(None)
             continue
         rule = moment_quadrature(ms, mean, scale)
         if rule is None:
             first_nan = t
-            out_m.append(None); out_mean.append(None); out_scale.append(None)
+            out_m.append(None); out_mean.append(None); out_scale.append(None); out_nell.append(None)
             continue
         w, x = rule
         u = [mp.tanh(xi) for xi in x]
@@ -180,7 +181,7 @@ def benes_bernoulli_cms(cms0, mean0, ys, dt=1e-2, tme_order=3, slope=5., dps=80,
         rule = moment_quadrature(ms, mean, scale)
         if rule is None:
             first_nan = t
-            out_m.append(None); out_mean.append(None); out_scale.append(None)
+            out_m.append(None); out_mean.append(None); out_scale.append(None); out_nell.append(None)
             continue
         w, x = rule
         p = [1 / (1 + mp.exp(-xi ** 3 / slope)) for xi in x]
@@ -193,6 +194,6 @@ def benes_bernoulli_cms(cms0, mean0, ys, dt=1e-2, tme_order=3, slope=5., dps=80,
               for n in range(M2)]
         mean, scale = new_mean, new_scale
         nell -= mp.log(py)
-        out_m.append(list(ms)); out_mean.append(mean); out_scale.append(scale)
+        out_m.append(list(ms)); out_mean.append(mean); out_scale.append(scale); out_nell.append(nell)
     return dict(moments=out_m, means=out_mean, scales=out_scale, nell=nell if first_nan < 0 else None,
-                first_nan=first_nan)
+                first_nan=first_nan, nell_cum=out_nell)

@@ -122,3 +122,40 @@ def test_multi_rank_run_without_rccl_is_a_visible_failure(tmp_path, allow, expec
         assert r['degraded'] is True and r['data'] == 'host' and r['error']
         assert r['gathered'] == [0.0, 1.0]
         assert r['status'] == expected
+
+
+@pytest.mark.parametrize('allow,expected', [(False, dist.EXIT_RCCL_FAILED), (True, 0)])
+def test_bench_self_launches_its_ranks(allow, expected):
+    """`python bench.py --gpus 2` without torchrun.  The parent only supervises (it never loads the
+    library or counts devices), starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank
+    0's single JSON line and leaves with the worst child status -- here, on a box without a GPU, the RCCL failure status
+    3 (0 with --allow-host-gather).  --dry-run stops after the communicator: no workload, no kernel."""
+    import json
+    env = dict(os.environ, MFS_RCCL_INIT_TIMEOUT='30', HIP_VISIBLE_DEVICES='')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'] + (['--allow-host-gather'] if allow else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=300)
+    assert r.returncode == expected, r.stderr.decode()[-600:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['dry_run'] is True and line['nll_allgather_ok'] is False
+    assert 'FAILED' in line['nll_allgather']
+
+
+def test_bench_launcher_parent_never_touches_the_gpu_library():
+    """The launcher branch must run before anything of mfs_amd is imported: a parent that had initialised the GPU could
+    not safely start children (and on the driver's node it would hold a device the ranks need)."""
+    import ast
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'main')
+    launch_line = next(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, 'id', '') == 'launch_ranks')
+    first_import = min(n.lineno for n in ast.walk(main) if isinstance(n, (ast.Import, ast.ImportFrom)))
+    assert launch_line < first_import
+    launcher = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'launch_ranks')
+    imported = {a.name for n in ast.walk(launcher) if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names}
+    assert imported <= {'socket', 'subprocess', 'threading'}, imported
+    top = {a.name.split('.')[0] for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom)) for a in n.names}
+    assert 'mfs_amd' not in top and 'torch' not in top
