@@ -35,6 +35,7 @@ import json
 import os
 import re
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -56,10 +57,15 @@ WORKLOADS = {
     # SURVEY section 8d asks for the raw (and scaled) representation of config 2 next to the central one, with divergence counts
     'benes_bernoulli_N15_T1000_B4096_raw_tme3': ('benes', 15, 1000, 4096, 'raw', 'tme_3'),
     'benes_bernoulli_N15_T1000_B4096_scaled_tme3': ('benes', 15, 1000, 4096, 'scaled', 'tme_3'),
+    # config 2 with stable=True (mfs/utils.py:525-538: LDL^T completion where a pivot is negative) -- SURVEY 8f rank 2
+    'benes_bernoulli_N15_T1000_B4096_central_tme3_stable': ('benes', 15, 1000, 4096, 'central', 'tme_3', {'stable': 1}),
+    # ... and with the predict-half rule reconstructed from the posterior moments as the reference does (MFS_PREDICT_RULE=recompute)
+    'benes_bernoulli_N15_T1000_B4096_central_tme3_recompute': ('benes', 15, 1000, 4096, 'central', 'tme_3', {'recompute': 1}),
     'well_poisson_N7_T1000_B131072_central_tme_normal2': ('well', 7, 1000, 131072, 'central', 'tme_normal_2'),
     # BASELINE config 3 (dardel/convergence): OU / Gaussian, exact linear-Gaussian transition
     'ou_gaussian_N15_T1000_B1024_central': ('ou', 15, 1000, 1024, 'central', 'exact'),
     'ou_gaussian_N25_T1000_B1024_central': ('ou', 25, 1000, 1024, 'central', 'exact'),
+    'ou_gaussian_N15_T1000_B1024_central_stable': ('ou', 15, 1000, 1024, 'central', 'exact', {'stable': 1}),
     # BASELINE config 5 (d = 2): per-GPU shard of the 512-replicate batch is set with --B (128 on 4 GPUs)
     'prey_predator_N6_T500_B512_central_tme2': ('prey', 6, 500, 512, 'central', 'tme_2'),
     'prey_predator_N6_T500_B512_central_tme_normal2': ('prey', 6, 500, 512, 'central', 'tme_normal_2'),
@@ -75,6 +81,8 @@ OTHER_WORKLOADS = [
     ('benes_bernoulli_N15_T1000_B4096_raw_tme3', 0, 'config2_raw'),
     ('benes_bernoulli_N15_T1000_B4096_scaled_tme3', 0, 'config2_scaled'),
     ('benes_bernoulli_N15_T1000_B4096_central_tme_normal3', 0, 'config2_tme_normal3'),
+    ('benes_bernoulli_N15_T1000_B4096_central_tme3_stable', 0, 'config2_stable'),
+    ('benes_bernoulli_N15_T1000_B4096_central_tme3_recompute', 0, 'config2_recompute_rule'),
     ('ou_gaussian_N15_T1000_B1024_central', 0, 'config3_N15'),
     ('ou_gaussian_N25_T1000_B1024_central', 0, 'config3_N25'),
     ('well_poisson_N7_T1000_B131072_central_tme_normal2', 0, 'config4_shard_B131072'),
@@ -116,7 +124,9 @@ class Workload1D:
         from mfs_amd import _lib, synth, stats
         from mfs_amd.one_dim import filtering, moments, ss_models
         self.name = name
-        self.model, self.N, T0, B0, self.mode, self.transition = WORKLOADS[name]
+        self.model, self.N, T0, B0, self.mode, self.transition = WORKLOADS[name][:6]
+        self.flags = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else {}
+        self.stable = int(self.flags.get('stable', 0))
         self.B, self.T = B or B0, T or T0
         self.full_size = (self.B == B0 and self.T == T0)
         N, B, T = self.N, self.B, self.T
@@ -175,8 +185,8 @@ class Workload1D:
         self.d_nell = _lib.DeviceBuffer(B * 8)
         self.d_fn = _lib.DeviceBuffer(B * 4)
         self.plan = C.c_void_p()
-        _lib.check(L.mfs_plan_1d_create(C.byref(self.plan), C.byref(self.mstruct), _lib.MODE[self.mode], N, T, B, 0,
-                                        chunk, self.device))
+        _lib.check(L.mfs_plan_1d_create(C.byref(self.plan), C.byref(self.mstruct), _lib.MODE[self.mode], N, T, B,
+                                        self.stable, chunk, self.device))
         geo = [C.c_int() for _ in range(4)]
         _lib.check(L.mfs_plan_1d_geometry(self.plan, *[C.byref(g) for g in geo]))
         self.geometry = {'lanes_per_filter': geo[0].value, 'filters_per_block': geo[1].value, 'grid': geo[2].value,
@@ -185,10 +195,16 @@ class Workload1D:
 
     def launch(self, stream):
         from mfs_amd import _lib
-        _lib.check(_lib.lib().mfs_plan_1d_run(self.plan, self.d_m0.ptr, 0, self.d_mean0.ptr, self.d_scale0.ptr,
-                                              self.d_ys.ptr, self.d_mom.ptr if self.d_mom else None, self.d_means.ptr,
-                                              self.d_scales.ptr if self.d_scales else None, self.d_nell.ptr,
-                                              self.d_fn.ptr, stream))
+        if self.flags.get('recompute'):      # read by the library at every run (capi.hip: A/B switch of the predict-half rule)
+            os.environ['MFS_PREDICT_RULE'] = 'recompute'
+        try:
+            _lib.check(_lib.lib().mfs_plan_1d_run(self.plan, self.d_m0.ptr, 0, self.d_mean0.ptr, self.d_scale0.ptr,
+                                                  self.d_ys.ptr, self.d_mom.ptr if self.d_mom else None, self.d_means.ptr,
+                                                  self.d_scales.ptr if self.d_scales else None, self.d_nell.ptr,
+                                                  self.d_fn.ptr, stream))
+        finally:
+            if self.flags.get('recompute'):
+                os.environ.pop('MFS_PREDICT_RULE', None)
 
     def release(self):
         from mfs_amd import _lib
@@ -686,11 +702,12 @@ def cpu_baseline(args, w, res):
     from oracle import c_oracle, tme_sympy, models as om, parity
     model, N, T, mode, tables, lik, ic, ys = w.model, w.N, w.T, w.mode, w.tables, w.lik, w.ic, w.ys
     dev_nell, dev_first = res['nell'], np.where(res['first_nan'] >= 0, res['first_nan'], T)
-    # all host cores this process may run on, regardless of OMP_NUM_THREADS (torchrun exports OMP_NUM_THREADS=1)
-    try:
-        threads = len(os.sched_getaffinity(0))
-    except AttributeError:
-        threads = os.cpu_count() or 1
+    # threads: the cores this process can really use (cgroup quota, not the affinity mask: 256 OpenMP threads on a 16-CPU
+    # share time-slice each other), pinned one per core; the source is rebuilt with -march=native for this host
+    os.environ.setdefault('OMP_PROC_BIND', 'close')
+    os.environ.setdefault('OMP_PLACES', 'cores')
+    flags = c_oracle.use_native_build(os.path.join(tempfile.gettempdir(), f'mfs_oracle_native_{os.getuid()}'))
+    quota_cores, affinity = c_oracle.host_cores()
     # independent SymPy derivation of the coefficient tables where it is cheap (shared-parameter models)
     if model == 'benes':
         odt, _, _, odrift, odisp, _, _ = om.benes_bernoulli(N)
@@ -713,10 +730,15 @@ def cpu_baseline(args, w, res):
                                cf, tables.mean_x_coef, lik_kind, lp, want_moments=want_moments, nthreads=threads)
         return time.perf_counter() - t0, r
 
-    nb = min(ys.shape[0], 4 * threads)
-    el, r = run(nb, False)
-    rate = nb * T / el
-    nb = int(min(ys.shape[0], max(nb, rate * args.cpu_seconds / T)))
+    # the thread count that is fastest on a short probe (the quota may be invisible from inside the container)
+    probe = {}
+    for threads in sorted({c for c in (quota_cores, 8, 16, 32, 64, 128, affinity) if 1 <= c <= affinity}):
+        nbp = min(ys.shape[0], 4 * threads)
+        el, _ = run(nbp, False)
+        probe[threads] = nbp * T / el
+    threads = max(probe, key=probe.get)
+    rate = probe[threads]
+    nb = int(min(ys.shape[0], max(4 * threads, rate * args.cpu_seconds / T)))
     nb = min(nb, max(1, int(3e9 // (T * 2 * N * 8))))     # host-memory bound of the moment sample
     el, r = run(nb, True)
     cm, cmeans, cscales, cnell = r
@@ -727,7 +749,10 @@ def cpu_baseline(args, w, res):
     out = {'value': live / el, 'unit': 'filter-steps/s', 'cores': threads, 'kind': 'port',
            'sample': f'first {nb} replicates x T={T} of the same workload incl. all 2N moments, oracle/c/mfs_oracle.c, '
                      f'OpenMP x{threads}, {el:.1f} s; live steps only ({live / (nb * T):.2f} of nominal)',
-           'nominal_value': nb * T / el,
+           'nominal_value': nb * T / el, 'per_thread_value': live / el / threads,
+           'build': flags, 'threads': threads, 'affinity_mask_cpus': affinity, 'cgroup_quota_cpus': quota_cores,
+           'pinning': f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}",
+           'thread_probe_nominal_steps_per_s': {str(k): v for k, v in probe.items()},
            'replicates_finite_in_both': int(both.sum()),
            'replicates_finite_device_only': int((np.isfinite(dev_nell[:nb]) & ~np.isfinite(cnell)).sum()),
            'replicates_finite_cpu_only': int((~np.isfinite(dev_nell[:nb]) & np.isfinite(cnell)).sum()),

@@ -19,6 +19,11 @@ namespace mfs {
 KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // filled by the static registrars in filter1d_inst.hip
 Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
 Filter1dFastLaunch g_fast_filter_wide[MFS_MAX_N + 1][4];
+Filter1dFastLaunch g_fast_filter_ext[MFS_MAX_N + 1][4];
+Filter1dFastLaunch g_fast_filter_ext_wide[MFS_MAX_N + 1][4];
+int g_fast_ext_shift[MFS_MAX_N + 1][4];
+Quad1dLaunch g_quad_ext[MFS_MAX_N + 1][4];
+int g_quad_ext_lds[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
@@ -71,13 +76,16 @@ int check_model(const mfs_model_1d* m, int mode) {
 }
 
 // Kernel choice.  Default: the register-resident fast path with the smallest lane group that holds the N + 1 rows of
-// the extended Hankel matrix.  stable=1 (LDL^T completion breaks the tridiagonal structure) and MFS_SOLVER=dense use
-// the LDS-tile dense path.  MFS_LANES_PER_FILTER=16|32|64 overrides the group width (experiments).
+// the extended Hankel matrix; stable = 1 and odd moment counts run its extended variant (the LDL^T completion only changes
+// a rule when a pivot is not > 0: that rule alone takes the dense route, inside the same kernel).  MFS_SOLVER=dense uses
+// the LDS-tile dense path throughout.  MFS_LANES_PER_FILTER=16|32|64 overrides the group width (experiments; with
+// stable = 1 or an odd count a non-default width runs the dense path -- the extended variant exists for the default only).
 int pick_slot(int N, int stable, int odd_tail = 0) {
-    bool dense = stable != 0 || odd_tail != 0;
+    bool dense = false;
     if (const char* e = getenv("MFS_SOLVER")) dense = dense || (strcmp(e, "dense") == 0);
     int want = 0;
     if (const char* e = getenv("MFS_LANES_PER_FILTER")) want = atoi(e);
+    if ((stable != 0 || odd_tail != 0) && want != 0) dense = true;
     if (dense) {
         int gi = (N <= 16) ? 0 : (N <= 32) ? 1 : 2;
         if (want == 64) gi = 2;
@@ -100,6 +108,7 @@ struct mfs_plan_1d {
     int mode, N, T, B, stable, chunk, device, extra;
     int slot, G, fpb, grid, lds_bytes, lds_doubles;
     bool single_wave_per_simd = false;
+    bool ext = false;               // fast path, extended variant (stable = 1 or an odd moment count)
     double* d_coef = nullptr;
     double* d_lik = nullptr;
     double* c_mom = nullptr;
@@ -226,6 +235,11 @@ int mfs_plan_1d_create(mfs_plan_1d** plan, const mfs_model_1d* model, int mode, 
     p->grid = (B + p->fpb - 1) / p->fpb;
     p->lds_doubles = ke.lds_doubles_per_filter;
     if (slot >= 3) p->lds_doubles += ((model->degree + 4) & ~3) * 10;  // fast path: + model table [ceil4(degree + 1)][kCoefRows]
+    p->ext = slot >= 3 && (stable != 0 || extra != 0);
+    if (p->ext) {
+        if (!mfs::g_fast_filter_ext[N][slot - 3]) { delete p; return fail(MFS_EUNSUPPORTED, "no extended kernel for N = %d", N); }
+        p->lds_doubles += mfs::g_fast_ext_shift[N][slot - 3];
+    }
     p->lds_bytes = p->fpb * p->lds_doubles * 8;
     {   // blocks of the fast path are single waves: with at most one per SIMD the wide-register variant costs nothing
         int cus = 0;   // (hipDeviceGetAttribute: one integer, not the whole property structure, per plan)
@@ -271,8 +285,9 @@ int mfs_plan_1d_geometry(const mfs_plan_1d* p, int* lanes_per_filter, int* filte
 
 static hipError_t launch_filter(mfs_plan_1d* p, const mfs::Filter1dArgs& a, hipStream_t s) {
     if (p->slot >= 3) {
-        const mfs::Filter1dFastLaunch wide = mfs::g_fast_filter_wide[p->N][p->slot - 3];
-        return (wide && p->single_wave_per_simd ? wide : mfs::g_fast_filter[p->N][p->slot - 3])(a, p->grid, p->lds_doubles, s);
+        const mfs::Filter1dFastLaunch wide = (p->ext ? mfs::g_fast_filter_ext_wide : mfs::g_fast_filter_wide)[p->N][p->slot - 3];
+        const mfs::Filter1dFastLaunch narrow = (p->ext ? mfs::g_fast_filter_ext : mfs::g_fast_filter)[p->N][p->slot - 3];
+        return (wide && p->single_wave_per_simd ? wide : narrow)(a, p->grid, p->lds_doubles, s);
     }
     return mfs::g_table[p->N][p->slot].filter(a, p->grid, p->lds_bytes, s);
 }
@@ -527,7 +542,9 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     hipStream_t s = (hipStream_t)stream;
     const int G = ke.lanes_per_filter;
     const int fpb = ke.waves_per_block * (64 / G);
-    const int quad_lds = fpb * (slot >= 3 ? 2 * N : ke.lds_doubles_per_filter) * 8;
+    const bool ext = slot >= 3 && stable != 0;     // the completed rule of stable = 1 needs the extended tile
+    if (ext && !mfs::g_quad_ext[N][slot - 3]) return fail(MFS_EUNSUPPORTED, "no extended quadrature kernel for N = %d", N);
+    const int quad_lds = fpb * (ext ? mfs::g_quad_ext_lds[N][slot - 3] : slot >= 3 ? 2 * N : ke.lds_doubles_per_filter) * 8;
     double *d_ms = nullptr, *d_mean = nullptr, *d_scale = nullptr, *d_w = nullptr, *d_x = nullptr;
     mfs::Lease lease(device);
     hipError_t e = hipSuccess;
@@ -542,7 +559,7 @@ int mfs_quadrature_1d(int N, int B, const double* ms, const double* mean, const 
     if (e == hipSuccess && scale) e = hipMemcpyAsync(d_scale, scale, (size_t)B * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         mfs::Quad1dArgs a{B, stable, d_ms, d_mean, d_scale, d_w, d_x};
-        e = ke.quad(a, (B + fpb - 1) / fpb, quad_lds, s);
+        e = (ext ? mfs::g_quad_ext[N][slot - 3] : ke.quad)(a, (B + fpb - 1) / fpb, quad_lds, s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_weights, d_w, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipMemcpyAsync(out_nodes, d_x, (size_t)B * N * 8, hipMemcpyDeviceToHost, s);

@@ -379,6 +379,11 @@ struct FastTile {
     static constexpr int oLfac = (oLik + MFS_MAX_LIK + 1) & ~1;  // log(y!) for y = 0..kLfacMax (Poisson likelihood)
     static constexpr int oCoef = oLfac + 34;                    // model table, (degree + 1) * kCoefRows doubles
     static constexpr int fixedDoubles = oCoef;
+    // Extended variant (stable = 1): a rule whose LDL^T has a pivot that is not > 0 takes the dense route (`quadrature` of
+    // filter1d_kernel.hpp) in place -- its tiles [G -> R][K][rotations][v0][x][w] start at oTab like the contribution
+    // table, which is scratch while a rule is formed -- so the tables behind (lik, lfac, coef) move up by kExtShift.
+    static constexpr int kDenseEnd = (Tile<N>::oCoef + 1) & ~1;
+    static constexpr int kExtShift = (kDenseEnd > oLik) ? kDenseEnd - oLik : 0;
 };
 
 constexpr int kMaxEigIters = 64;
@@ -408,13 +413,72 @@ __device__ __forceinline__ double likelihood_fast(const int kind, const double* 
     return likelihood(kind, lp, y, x);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// stable = 1 (mfs/utils.py:525-538), the rule of a COMPLETED factor.  R = L diag(f_k), f_k = d_k < 0 ? eps : sqrt(d_k),
+// eps = 1e-8 ||G||_F, no longer satisfies R R^T = G -- but K = R^-1 H R^-T (quadtures.py:128-129) is STILL tridiagonal.  The
+// rows of L^-1 are the monic polynomials pi_j orthogonal for the (now indefinite) moment functional -- all that needs is
+// non-zero leading minors -- so M = L^-1 H L^-T has M_jj = <x pi_j, pi_j> = alpha_j d_j, M_{j+1,j} = <x pi_j, pi_{j+1}> = d_{j+1}
+// and zeros elsewhere, whatever the signs of the d_j, and K = F^-1 M F^-1, F = diag(f):
+//     K_jj = alpha_j s_j,    K_{j+1,j}^2 = (d_{j+1} / d_j) s_j s_{j+1},    s_j = d_j / f_j^2  (1 where d_j > 0, d_j / eps^2 < 0 else)
+// with alpha_j and d_{j+1} / d_j the very ratios every other rule is built from.  (Checked in 80-digit arithmetic on the
+// completed rules of config 2: the dense K's off-tridiagonal entries are < 1e-63 and these formulae hold to 1e-59; in fp64 the
+// reference's dense K carries rounding noise amplified by 1 / eps^2 there, which is why two fp64 implementations of the
+// reference part ways after a completion.)  The completed rule therefore costs one LDS pass for ||G||_F and N multiplications
+// on top of a plain rule.  Its first-row eigenvector components come from the twisted factorisation below.
+
+// Squared first component of the normalised eigenvector of the symmetric tridiagonal (a, b2) at the eigenvalue lam, from the
+// twisted factorisation N_r D_r N_r^T of T - lam I (Parlett & Dhillon; LAPACK dlar1v): forward pivots Dp, backward pivots Dm,
+// the twist where |gamma_r| = |Dp_r + Dm_r - (a_r - lam)| is smallest, z_r = 1 and
+//   z_j^2 = b2_j / Dp_j^2 z_{j+1}^2 (j < r),    z_j^2 = b2_{j-1} / Dm_j^2 z_{j-1}^2 (j > r).
+// The three-term recurrence the plain rules use for the same number is unstable when T is nearly reducible, which a
+// completed factor makes it (off by up to 0.5 on config-2 cases; this form agrees with LAPACK's eigenvectors to 1e-13).
+template <int N>
+__device__ __forceinline__ double twisted_weight(const double (&a)[N], const double (&b2)[N], const double lam) {
+    double ip[N], im[N], gam[N];    // 1 / Dp, 1 / Dm
+    double d = a[0] - lam;
+    static_for<0, N>([&](auto Jc) {
+        constexpr int j = Jc;
+        gam[j] = d;
+        ip[j] = rcp_nr((d == 0.0) ? 1e-290 : d);
+        if constexpr (j + 1 < N) d = fma(-b2[j], ip[j], a[j + 1] - lam);
+    });
+    d = a[N - 1] - lam;
+    static_for<0, N>([&](auto Jc) {
+        constexpr int j = N - 1 - Jc;
+        gam[j] += d - (a[j] - lam);
+        im[j] = rcp_nr((d == 0.0) ? 1e-290 : d);
+        if constexpr (j > 0) d = fma(-b2[j - 1], im[j], a[j - 1] - lam);
+    });
+    int r = 0;
+    double gmin = fabs(gam[0]);
+    static_for<1, N>([&](auto Jc) { const double gj = fabs(gam[Jc]); const bool less = gj < gmin; r = less ? (int)Jc : r; gmin = less ? gj : gmin; });
+    double zz = 1.0, sm = 1.0;
+    static_for<0, N - 1>([&](auto Jc) {
+        constexpr int j = N - 2 - Jc;
+        const bool take = j < r;
+        const double zn = zz * (b2[j] * ip[j] * ip[j]);
+        zz = take ? zn : zz;
+        sm += take ? zn : 0.0;
+    });
+    double yy = 1.0;
+    static_for<1, N>([&](auto Jc) {
+        constexpr int j = Jc;
+        const bool take = j > r;
+        const double yn = yy * (b2[j - 1] * im[j] * im[j]);
+        yy = take ? yn : yy;
+        sm += take ? yn : 0.0;
+    });
+    return zz * rcp_sat(sm);
+}
+
 // Gauss quadrature from the 2N moments in LDS.  Lane l < N returns node x and weight w; other lanes get w = 0.
 // Returns the group-uniform poison flag (a Cholesky pivot was not > 0, as LAPACK potrf / XLA report).
-template <int N, int G>
+template <int N, int G, bool EXT = false>
 __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, const int l, const int grp,
                                                 const double mean, const double scale, double& x_out, double& w_out,
                                                 double& lam_io, const bool recentre = false, const bool atoms = false,
-                                                const double w_atom = 0.0) {
+                                                const double w_atom = 0.0, double* __restrict__ S = nullptr,
+                                                const int stable = 0, int* dense_rules = nullptr) {
     static_assert(N + 1 <= G, "needs one lane per row of the extended Hankel matrix");
     F1_STAMP_BEGIN;
     // -- row l of the extended Hankel matrix: g[j] = m[l + j], l = 0..N (quadtures.py:124-125)
@@ -540,7 +604,34 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 
     F1_STAMP(1);
     double lam = 0.0, w = 0.0;
-    if (atoms) {
+    double a[N], b2[N];              // the Jacobi matrix of the rule: diagonal and squared sub-diagonal (group-uniform)
+    bool use_atoms = atoms, twisted = false;
+    if constexpr (EXT) {
+        // stable = 1 (mfs/utils.py:525-538): with every pivot > 0, R = L sqrt(D) IS the Cholesky factor and the rule is the
+        // one formed below.  A pivot that is not > 0 (group-uniform; ~0.1 % of the rules of config 2) ends the Hankel
+        // structure -- R R^T != G -- and only then the rule is that of the completed factor (completed_tridiagonal).
+        if (stable && poisoned) {
+            if (dense_rules) *dense_rules += 1;
+            double fro = 0.0;
+            static_for<0, N>([&](auto Jc) { const double v = mom[((l < N) ? l : N - 1) + Jc]; fro = fma(v, v, fro); });
+            fro = gsum<G>((l < N) ? fro : 0.0);                 // ||G||_F^2
+            const double ieps2 = 1e16 / fro;                    // 1 / eps^2
+            const double qn = __builtin_nan("");
+            double sj[N];
+            static_for<0, N>([&](auto Jc) { sj[Jc] = (piv[Jc] > 0.0) ? 1.0 : ((piv[Jc] < 0.0) ? piv[Jc] * ieps2 : qn); });   // d_j = 0: 0 / 0 upstream
+            static_for<0, N>([&](auto Jc) {
+                constexpr int j = Jc;
+                double aj = sub[j] * ipiv[j];
+                if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
+                a[j] = aj * sj[j];
+                if constexpr (j < N - 1) b2[j] = (piv[j + 1] * ipiv[j]) * (sj[j] * sj[j + 1]); else b2[j] = 0.0;
+            });
+            use_atoms = false;
+            twisted = true;
+            poisoned = false;
+        }
+    }
+    if (use_atoms) {
         // The moments are those of an N-atom measure whose atoms the caller holds (the posterior of an update: nodes
         // x_i, weights w_i l(y, x_i) / p_y), and the N-node Gauss rule of an N-atom measure IS that measure: the
         // Cholesky above has decided the poisoning exactly as the reference's does, the eigen-decomposition of
@@ -550,22 +641,50 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
         w = w_atom;
     } else {
         // -- Jacobi matrix: a_j = K_jj, b2_j = K_{j+1,j}^2, and the weight normalisers c_j = piv_0 / piv_j
-        double a[N], b2[N];
+        if (!twisted) {
+            static_for<0, N>([&](auto Jc) {
+                constexpr int j = Jc;
+                double aj = sub[j] * ipiv[j];
+                if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
+                a[j] = aj;
+                if constexpr (j < N - 1) b2[j] = piv[j + 1] * ipiv[j]; else b2[j] = 0.0;
+            });
+        }
         double amin = 1.79e308, amax = -1.79e308, bmax2 = 0.0;
         static_for<0, N>([&](auto Jc) {
             constexpr int j = Jc;
-            double aj = sub[j] * ipiv[j];
-            if constexpr (j > 0) aj -= sub[j - 1] * ipiv[j - 1];
-            a[j] = aj;
-            if constexpr (j < N - 1) {
-                b2[j] = piv[j + 1] * ipiv[j];
-                bmax2 = vmax_f64(bmax2, b2[j]);
-            } else {
-                b2[j] = 0.0;
-            }
-            amin = vmin_f64(amin, aj);
-            amax = vmax_f64(amax, aj);
+            if constexpr (j < N - 1) bmax2 = vmax_f64(bmax2, b2[j]);
+            amin = vmin_f64(amin, a[j]);
+            amax = vmax_f64(amax, a[j]);
         });
+        if constexpr (EXT) {
+            // The eigenvalue iteration below resolves the spectrum to ~1e-15 of its WIDTH, and accepts on that scale.  A
+            // completed rule can carry a node far outside the bulk with a negligible weight (an indefinite start: 1e13
+            // standard deviations away); the rules that follow are graded the same way, and their bulk nodes would come
+            // out with an error of 1e-15 x width.  Wider than 1e7 standard deviations of the rule's own measure
+            // (b2_0 = its variance in rule units) -- or anything not finite -- takes the dense route: cyclic Jacobi on the
+            // full K in the LDS tiles that alias the contribution table (`quadrature`, filter1d_kernel.hpp), which keeps the
+            // relative accuracy of small eigenvalues.  Its eigenvalues come in no particular order (the filter's sums do
+            // not care; as a start of the next iteration they only steer).
+            const double wd0 = (amax - amin) + 4.0 * sqrt(bmax2);
+            if (stable && !(wd0 * wd0 <= 1e14 * b2[0])) {
+                if (dense_rules) *dense_rules += 1000;
+#ifdef MFS_EXT_DEBUG
+                const long long tj0 = clock64();
+#endif
+                quadrature<N, G>(S, l, mean, scale, 1);
+#ifdef MFS_EXT_DEBUG
+                if (dense_rules) dense_rules[2] += (int)((clock64() - tj0) >> 4);
+#endif
+                const int li2 = (l < N) ? l : N - 1;
+                const double xd = S[Tile<N>::oX + li2], wdn = S[Tile<N>::oW + li2];
+                wave_sync();                               // (every lane has its node before the tiles turn into the table again)
+                lam_io = (xd - mean) / scale;
+                x_out = (l < N) ? xd : mean;
+                w_out = (l < N) ? wdn : 0.0;
+                return !finite(wdn);
+            }
+        }
 
         F1_STAMP(2);
         if (!poisoned) {
@@ -582,6 +701,11 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
             double lo = amin - rad - 1e-3 * width, hi = amax + rad + 1e-3 * width;
             const double wscale = fmax(fabs(lo), fabs(hi));
             const double tol = 1e-15 * wscale;  // ~4.5 eps ||K||: LAPACK-level absolute accuracy
+            // the scale the early-acceptance rules below reason on: the spectrum's extent -- which for a rule with a stray
+            // far node (extended variant: up to 1e7 standard deviations pass the test above) says nothing about the gaps
+            // between the bulk eigenvalues, so there it is capped at 32 standard deviations of the rule's measure
+            double wacc = wscale;
+            if constexpr (EXT) wacc = fmin(wscale, 32.0 * sqrt(b2[0]));
             const int k = (l < N) ? l : N - 1;
             // start from this lane's eigenvalue of the previous rule when there is one (the Jacobi matrix moves little
             // between consecutive quadratures), else spread the lanes over the bracket
@@ -656,9 +780,24 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                     //  update-half rule -- see the kernel.)
                     const double nwt = -p1 * d1;   // sign of the Newton step -p/p'
                     const bool ahead = right ? (nwt > 0.0) : (nwt < 0.0);
-                    const bool near = ok & ahead & ((double)N * fabs(p1) <= (3e-7 * wscale) * fabs(d1));
-                    const bool conv_n = (ok & (step <= tol)) | (ok & (step <= kLagStop * wscale) & (step <= 1e-2 * prev_step)) |
-                                        near | (hi_n - lo_n <= tol) | ((p1 == 0.0) & (right | left));
+                    const bool near = ok & ahead & ((double)N * fabs(p1) <= (3e-7 * wacc) * fabs(d1));
+                    bool conv_n;
+                    if constexpr (EXT) {
+                        // A step below the tolerance is convergence only when the root it approaches lies AHEAD.  After a
+                        // completed or dense rule the eigenvalues come back in another order, and a lane can start ON a
+                        // root that is not its own (the atoms of a posterior survive a step to the last bit): travelling
+                        // away from that root Laguerre's first steps are as small as the distance to it -- or zero -- and
+                        // would be mistaken for convergence (two lanes on one eigenvalue, a rule of weight 1.5).  Such a
+                        // lane is pushed off by a few tolerances instead; the count then says on which side its root lies.
+                        const bool leaving = ok & !ahead & (step <= tol) & !((p1 == 0.0) & right);
+                        const double push = right ? x + 4.0 * tol : x - 4.0 * tol;
+                        xn = leaving ? (((push > lo_n) & (push < hi_n)) ? push : mid) : xn;
+                        conv_n = (ok & !leaving & (step <= tol)) | (ok & (step <= kLagStop * wacc) & (step <= 1e-2 * prev_step)) |
+                                 near | (hi_n - lo_n <= tol) | ((p1 == 0.0) & right);
+                    } else {
+                        conv_n = (ok & (step <= tol)) | (ok & (step <= kLagStop * wacc) & (step <= 1e-2 * prev_step)) |
+                                 near | (hi_n - lo_n <= tol) | ((p1 == 0.0) & (right | left));
+                    }
                     lo = conv ? lo : lo_n;
                     hi = conv ? hi : hi_n;
                     prev_step = conv ? prev_step : (ok ? step : 0.0);
@@ -679,6 +818,7 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
                 p0 = p1; p1 = pn;
             });
             w = rcp_sat(piv[0] * (acc + acc2));   // the sum overflows for the outermost nodes of large rules: weight 0, not NaN
+            if constexpr (EXT) { if (twisted) w = twisted_weight<N>(a, b2, lam); }
             F1_STAMP(4);
         }
     }
@@ -698,10 +838,14 @@ __device__ __forceinline__ bool quadrature_fast(const double* __restrict__ mom, 
 // time loop does not fit in 256 registers (N = 14..16: a few pointers spill to scratch, and every reload is a
 // s_waitcnt vmcnt(0) in the step) also exist with OCC = 1 (512 registers), which the plan picks when the batch puts no
 // more than one wave on a SIMD anyway.
-template <int N, int G, int WPB, int OCC>
+// EXT = the extended variant: stable = 1 (LDL^T completion where a pivot is not > 0, see quadrature_fast) and odd moment
+// counts (`extra`: one more moment per step, formed in the update and never read by a rule, filtering.py:65-66).  A separate
+// instantiation, so that the plain kernel's registers and instruction stream are untouched.
+template <int N, int G, int WPB, int OCC, bool EXT = false>
 __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filter1dArgs a, const int lds_doubles) {
     using L = FastTile<N, G>;
     constexpr int M2 = L::M2, TLD = L::TLD;
+    constexpr int kShift = EXT ? L::kExtShift : 0;
     constexpr int FPW = 64 / G;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -712,9 +856,11 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
     double* S = smem + (size_t)slot * lds_doubles;
     double* mom = S + L::oMom;
     double* TAB = S + L::oTab;
-    const double* coef = S + L::oCoef;
-    const double* lp = S + L::oLik;
+    const double* coef = S + L::oCoef + kShift;
+    const double* lp = S + L::oLik + kShift;
+    double* lfac = S + L::oLfac + kShift;
     const int J1 = a.degree + 1;
+    const int MS = EXT ? M2 + a.extra : M2;        // moments per row of m0 / out_moments
 
     {   // stage the model tables and the carry
         const double* src = a.coef + (a.coef_batched ? (size_t)b * a.n_rows * J1 : 0);
@@ -724,17 +870,17 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
             // between stay zero, so the time loop reads both from fixed registers whatever the number of terms
             int sr = r;
             if (a.trans_kind == MFS_TRANS_OPERATOR) sr = (r == MFS_MAX_TERMS) ? a.n_terms : (r < a.n_terms) ? r : a.n_rows;
-            S[L::oCoef + e] = (sr < a.n_rows && j < J1) ? src[sr * J1 + j] : 0.0;
+            S[L::oCoef + kShift + e] = (sr < a.n_rows && j < J1) ? src[sr * J1 + j] : 0.0;
         }
         const double* ls = a.lik + (a.lik_batched ? (size_t)b * a.n_lik : 0);
-        for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + e] = (e < a.n_lik) ? ls[e] : 0.0;
+        for (int e = l; e < MFS_MAX_LIK; e += G) S[L::oLik + kShift + e] = (e < a.n_lik) ? ls[e] : 0.0;
         if (a.lik_kind == MFS_LIK_POISSON_SOFTPLUS)
-            for (int e = l; e <= kLfacMax; e += G) S[L::oLfac + e] = log_factorial((double)e);
+            for (int e = l; e <= kLfacMax; e += G) lfac[e] = log_factorial((double)e);
     }
     double mean = 0.0, scale = 1.0, nell = 0.0;
     int first_nan = -1;
     if (a.t_begin == 0) {
-        const double* src = a.m0 + (a.m0_batched ? (size_t)b * M2 : 0);
+        const double* src = a.m0 + (a.m0_batched ? (size_t)b * MS : 0);
         for (int n = l; n < M2; n += G) mom[n] = src[n];
         if (a.mode != MFS_MODE_RAW) mean = a.mean0[a.m0_batched ? b : 0];
         if (a.mode == MFS_MODE_SCALED) scale = a.scale0[a.m0_batched ? b : 0];
@@ -770,6 +916,9 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
         have_atoms = true;
     }
     double ywin = 0.0;                  // window of measurements (16 steps, or G when G < 16), one per lane
+#ifdef MFS_EXT_DEBUG
+    int dbg_dense[3] = {0, 0, 0};       // diagnostic build: rules of this replicate that took the slow routes; their cycles
+#endif
 
     for (int t = a.t_begin; t < a.t_end; ++t) {
         // measurements: one coalesced 128-byte load per group every 16 steps, handed out by a lane shuffle
@@ -796,7 +945,11 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
                 // predict half: the rule of the posterior moments is the posterior's own atoms (see quadrature_fast); the
                 // reference's recomputation stays available as an A/B switch
                 const bool atoms = (half == 0) & have_atoms & (a.recompute_rule == 0);
-                quadrature_fast<N, G>(mom, l, grp, mean, scale, x, w, lam_io, half == 1, atoms, gW);
+#ifdef MFS_EXT_DEBUG
+                quadrature_fast<N, G, EXT>(mom, l, grp, mean, scale, x, w, lam_io, half == 1, atoms, gW, S, a.stable, dbg_dense);
+#else
+                quadrature_fast<N, G, EXT>(mom, l, grp, mean, scale, x, w, lam_io, half == 1, atoms, gW, S, a.stable);
+#endif
                 if (half == 0) gB = lam_io;
 #ifdef MFS_1D_STAMPS
                 if (blockIdx.x == 0 && threadIdx.x == 0) g_1d_stamps[11 + half] += g_1d_stamps[10] - it_before;
@@ -855,7 +1008,7 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
                     }
                 } else {
                     // ---- update (filtering.py:82-85 / 151-157 / 228-236)
-                    const double wl = node ? w * likelihood_fast(a.lik_kind, lp, S + L::oLfac, y, x) : 0.0;
+                    const double wl = node ? w * likelihood_fast(a.lik_kind, lp, lfac, y, x) : 0.0;
                     py = gsum<G>(wl);
                     ipy = rcp_nr(py);
                     if (a.mode != MFS_MODE_RAW) {
@@ -882,6 +1035,7 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
                             row[n] = pw[n & 3];
                             pw[n & 3] *= dx4;
                         }
+                        if constexpr (EXT) row[M2] = pw[M2 & 3];    // wl dx^(2N): the row's pad slot (odd moment counts)
                     }
                     nell -= fast_log(py);
                 }
@@ -891,8 +1045,10 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
                     // together in three partial sums each -- a dependent add costs several issue slots on one wave
                     const int n0 = l, n1 = l + G;
                     const bool has0 = n0 < M2, has1 = n1 < M2;
-                    const double* t0 = TAB + (has0 ? n0 : 0);
-                    const double* t1 = TAB + (has1 ? n1 : 0);
+                    const bool tails = EXT && a.extra && half == 1;               // odd count: the pad column is summed too,
+                    const bool tail0 = tails && n0 == M2, tail1 = tails && n1 == M2;  // by the lane whose slot is order 2N
+                    const double* t0 = TAB + ((has0 || tail0) ? n0 : 0);
+                    const double* t1 = TAB + ((has1 || tail1) ? n1 : 0);
                     double c0[N], c1[N];
 #pragma unroll
                     for (int i = 0; i < N; ++i) { c0[i] = t0[i * TLD]; c1[i] = t1[i * TLD]; }
@@ -904,7 +1060,7 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
                     if (half != 0) { acc0 *= ipy; acc1 *= ipy; }
                     if (has0) { mom[n0] = acc0; bad |= !finite(acc0); }
                     if (has1) { mom[n1] = acc1; bad |= !finite(acc1); }
-                    out0 = acc0; out1 = acc1;
+                    out0 = acc0; out1 = acc1;     // (with an odd count out1 of lane 2N - G is the order-2N moment: written out, never carried)
                 }
                 wave_sync();
                 F1_STAMP(7);
@@ -920,9 +1076,9 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
             wave_sync();
         }
         if (a.out_mom) {
-            double* dst = a.out_mom + ((size_t)b * a.T + t) * M2;
-            if (l < M2) dst[l] = out0;
-            if (l + G < M2) dst[l + G] = out1;
+            double* dst = a.out_mom + ((size_t)b * a.T + t) * MS;
+            if (l < MS) dst[l] = out0;
+            if (l + G < MS) dst[l + G] = out1;
         }
         if (l == 0) {
             if (a.out_mean) a.out_mean[(size_t)b * a.T + t] = mean;
@@ -933,6 +1089,9 @@ __global__ __launch_bounds__(WPB * 64, OCC) void filter1d_fast_kernel(const Filt
         if (l == 0) {
             a.out_nell[b] = nell;
             if (a.out_first_nan) a.out_first_nan[b] = first_nan;
+#ifdef MFS_EXT_DEBUG
+            if (EXT && a.out_mean && a.T > 3) { a.out_mean[(size_t)b * a.T + a.T - 1] = (double)dbg_dense[0]; a.out_mean[(size_t)b * a.T + a.T - 2] = (double)dbg_dense[1]; a.out_mean[(size_t)b * a.T + a.T - 3] = 16.0 * (double)dbg_dense[2]; }   // diagnostic build only
+#endif
         }
     } else {
         for (int n = l; n < M2; n += G) a.c_mom[(size_t)b * M2 + n] = mom[n];
@@ -959,6 +1118,31 @@ __global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_kernel(const Quad1
     double x, w;
     double lam_dummy = __builtin_nan("");
     quadrature_fast<N, G>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w, lam_dummy);
+    if (l < N) {
+        a.out_w[(size_t)b * N + l] = w;
+        a.out_x[(size_t)b * N + l] = x;
+    }
+}
+
+// the same with stable = 1: the completed rule needs the per-filter tile of the extended filter kernel
+template <int N, int G, int WPB>
+__global__ __launch_bounds__(WPB * 64) void quadrature1d_fast_ext_kernel(const Quad1dArgs a) {
+    using L = FastTile<N, G>;
+    constexpr int M2 = 2 * N, kStride = L::oLik + L::kExtShift;
+    constexpr int FPW = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / G, l = lane - grp * G;
+    const int slot = wave * FPW + grp;
+    const int b = blockIdx.x * (WPB * FPW) + slot;
+    if (b >= a.B) return;
+    double* S = smem + (size_t)slot * kStride;
+    for (int n = l; n < M2; n += G) S[n] = a.ms[(size_t)b * M2 + n];
+    wave_sync();
+    double x, w;
+    double lam_dummy = __builtin_nan("");
+    quadrature_fast<N, G, true>(S, l, grp, a.mean ? a.mean[b] : 0.0, a.scale ? a.scale[b] : 1.0, x, w, lam_dummy, false, false,
+                                0.0, S, a.stable);
     if (l < N) {
         a.out_w[(size_t)b * N + l] = w;
         a.out_x[(size_t)b * N + l] = x;

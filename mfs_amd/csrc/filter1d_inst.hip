@@ -12,6 +12,11 @@ namespace mfs {
 extern KernelEntry g_table[MFS_MAX_N + 1][kSlots];  // defined in capi.hip
 extern Filter1dFastLaunch g_fast_filter[MFS_MAX_N + 1][4];
 extern Filter1dFastLaunch g_fast_filter_wide[MFS_MAX_N + 1][4];  // nullptr where the default budget does not spill
+extern Filter1dFastLaunch g_fast_filter_ext[MFS_MAX_N + 1][4];       // extended variant (stable = 1, odd moment counts); default lane count only
+extern Filter1dFastLaunch g_fast_filter_ext_wide[MFS_MAX_N + 1][4];
+extern Quad1dLaunch g_quad_ext[MFS_MAX_N + 1][4];                     // quadrature entry with stable = 1
+extern int g_quad_ext_lds[MFS_MAX_N + 1][4];                         // its LDS doubles per filter
+extern int g_fast_ext_shift[MFS_MAX_N + 1][4];                      // extra LDS doubles per filter of the extended variant
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 extern Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 
@@ -50,10 +55,10 @@ void reg(int gi) {
 }
 
 // ---- fast (register-resident) path: single-wave workgroups, LDS = filters per wave x (fixed + model table)
-template <int N, int G, int OCC>
+template <int N, int G, int OCC, bool EXT = false>
 hipError_t launch_filter_fast(const Filter1dArgs& a, int grid, int lds_doubles, hipStream_t s) {
-    if (hipError_t e = ensure_dynamic_lds<&filter1d_fast_kernel<N, G, 1, OCC>>(); e != hipSuccess) return e;
-    hipLaunchKernelGGL((filter1d_fast_kernel<N, G, 1, OCC>), dim3(grid), dim3(64), (64 / G) * lds_doubles * 8, s, a,
+    if (hipError_t e = ensure_dynamic_lds<&filter1d_fast_kernel<N, G, 1, OCC, EXT>>(); e != hipSuccess) return e;
+    hipLaunchKernelGGL((filter1d_fast_kernel<N, G, 1, OCC, EXT>), dim3(grid), dim3(64), (64 / G) * lds_doubles * 8, s, a,
                        lds_doubles);
     return hipGetLastError();
 }
@@ -61,6 +66,13 @@ hipError_t launch_filter_fast(const Filter1dArgs& a, int grid, int lds_doubles, 
 template <int N, int G>
 hipError_t launch_quad_fast(const Quad1dArgs& a, int grid, int lds, hipStream_t s) {
     hipLaunchKernelGGL((quadrature1d_fast_kernel<N, G, 1>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int N, int G>
+hipError_t launch_quad_fast_ext(const Quad1dArgs& a, int grid, int lds, hipStream_t s) {
+    if (hipError_t e = ensure_dynamic_lds<&quadrature1d_fast_ext_kernel<N, G, 1>>(); e != hipSuccess) return e;
+    hipLaunchKernelGGL((quadrature1d_fast_ext_kernel<N, G, 1>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -76,6 +88,14 @@ void reg_fast(int gi) {
     KernelEntry& e = g_table[N][3 + gi];  // gi: 0..2 = G 16 / 32 / 64, 3 = G 8
     constexpr int occ = (N <= 16) ? 2 : 1;
     g_fast_filter[N][gi] = &launch_filter_fast<N, G, occ>;
+    // stable = 1 / odd moment counts: the extended variant, for the default lane count of the order (others: dense path)
+    if constexpr (G == ((N + 1 <= 8) ? 8 : (N + 1 <= 16) ? 16 : (N + 1 <= 32) ? 32 : 64)) {
+        g_fast_filter_ext[N][gi] = &launch_filter_fast<N, G, occ, true>;
+        g_fast_ext_shift[N][gi] = FastTile<N, G>::kExtShift;
+        g_quad_ext[N][gi] = &launch_quad_fast_ext<N, G>;
+        g_quad_ext_lds[N][gi] = FastTile<N, G>::oLik + FastTile<N, G>::kExtShift;
+        if constexpr (N >= 14 && N <= 16) g_fast_filter_ext_wide[N][gi] = &launch_filter_fast<N, G, 1, true>;
+    }
     // one-wave-per-SIMD register budget for the orders that spill at two (their default lane count only)
     if constexpr (N >= 14 && N <= 16 && G == ((N + 1 <= 16) ? 16 : 32)) g_fast_filter_wide[N][gi] = &launch_filter_fast<N, G, 1>;
     e.filter = nullptr;

@@ -139,8 +139,14 @@ static int tql2(int n, double* V, double* d, double* e) {
     return 0;
 }
 
-/* ---- moment quadrature (quadtures.py:83-133).  Returns 0, or 1 when poisoned (outputs set to NaN). ---- */
-static int quadrature(int n, const double* ms, double mean, double scale, int stable, double* w, double* x) {
+/* diagnostics of stable = 1: rules whose LDL^T had a negative pivot (completed by eps), counted per replicate and half-step
+ * when a counter array [B][2] has been registered (tests / tools only; not thread-safe across concurrent callers) */
+static int* g_completions = 0;
+void mfs_oracle_set_completion_counter(int* counts) { g_completions = counts; }
+
+/* ---- moment quadrature (quadtures.py:83-133).  Returns 0, or 1 when poisoned (outputs set to NaN); *completed = 1 when
+ *      stable and some pivot was negative. ---- */
+static int quadrature(int n, const double* ms, double mean, double scale, int stable, double* w, double* x, int* completed) {
     double R[MAXN * MAXN], K[MAXN * MAXN], d[MAXN], e[MAXN];
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) { R[i * n + j] = ms[i + j]; K[i * n + j] = ms[i + j + 1]; }
@@ -174,6 +180,7 @@ static int quadrature(int n, const double* ms, double mean, double scale, int st
         }
         for (int j = 0; j < n; j++) {
             const double f = dd[j] < 0.0 ? eps : sqrt(dd[j]);
+            if (dd[j] < 0.0 && completed) *completed = 1;
             R[j * n + j] = f;
             for (int i = j + 1; i < n; i++) R[i * n + j] *= f;
         }
@@ -248,7 +255,9 @@ int mfs_oracle_filter_1d(int mode, int N, int T, int B, int trans_kind, int umap
         for (int t = 0; t < T; t++) {
             const double y = ys[(size_t)b * T + t];
             /* prediction */
-            quadrature(N, ms, mean, scale, stable, w, x);
+            int comp = 0;
+            quadrature(N, ms, mean, scale, stable, w, x, &comp);
+            if (comp && g_completions) g_completions[2 * b] += 1;
             double c = 0.0, isc = 1.0;
             if (mode) {
                 double mu = 0.0, var = 0.0;
@@ -289,7 +298,9 @@ int mfs_oracle_filter_1d(int mode, int N, int T, int B, int trans_kind, int umap
             }
             memcpy(ms, nw, sizeof(double) * M2);
             /* update */
-            quadrature(N, ms, mean, scale, stable, w, x);
+            comp = 0;
+            quadrature(N, ms, mean, scale, stable, w, x, &comp);
+            if (comp && g_completions) g_completions[2 * b + 1] += 1;
             double py = 0.0, mx = 0.0;
             for (int i = 0; i < N; i++) { w[i] *= likelihood(lik_kind, lpp, y, x[i]); py += w[i]; mx += w[i] * x[i]; }
             if (mode) { mean = mx / py; c = mean; }
@@ -320,7 +331,7 @@ int mfs_oracle_quadrature_1d(int N, int B, const double* ms, const double* mean,
     if (N < 2 || N > MAXN) return -1;
     for (int b = 0; b < B; b++)
         quadrature(N, ms + (size_t)b * 2 * N, mean ? mean[b] : 0.0, scale ? scale[b] : 1.0, stable, w + (size_t)b * N,
-                   x + (size_t)b * N);
+                   x + (size_t)b * N, 0);
     return 0;
 }
 

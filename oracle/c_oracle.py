@@ -11,6 +11,50 @@ import numpy as np
 _HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'c')
 _PATH = os.path.join(_HERE, 'libmfs_oracle.so')
 _lib = None
+build_flags = '-O3 -march=x86-64-v3 -fopenmp (prebuilt, portable)'
+
+
+def use_native_build(outdir):
+    """bench.py's cpu_baseline leg: compile the same source with -march=native for THIS host (the prebuilt .so is
+    x86-64-v3 because it travels between machines) into `outdir` and use that build from now on.  Must be called before
+    the first lib(); returns the flags in use (the portable build's when gcc is missing or fails)."""
+    global _PATH, build_flags
+    if _lib is not None:
+        return build_flags
+    try:
+        os.makedirs(outdir, exist_ok=True)
+        out = os.path.join(outdir, 'libmfs_oracle_native.so')
+        subprocess.check_call(['gcc', '-O3', '-march=native', '-fopenmp', '-fPIC', '-shared', '-o', out,
+                               os.path.join(_HERE, 'mfs_oracle.c'), '-lm'], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _PATH, build_flags = out, '-O3 -march=native -fopenmp (built on this host)'
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    return build_flags
+
+
+def host_cores():
+    """(cores this process can actually use, affinity-mask size): the cgroup CPU quota bounds the former -- a container
+    with a 16-CPU share on a 256-thread host shows 256 in its affinity mask, and 256 OpenMP threads then time-slice 16."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:            # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()
+            if q != 'max':
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return cores, aff
 
 
 def lib():

@@ -5,13 +5,14 @@ NumPy/LAPACK restatement under oracle/ -- pinned by the reference's analytic tes
 synthetic measurements, and committed so that the GPU parity tests compare the HIP path with FROZEN numbers instead
 of recomputing the oracle on the GPU box.  Run in the build container:
 
-    python tests/golden/make_filter_golden.py [cfg1 cfg2 cfg2env cfg3 cfg4 cfg5 ...] [--procs P]
+    python tests/golden/make_filter_golden.py [cfg1 cfg2 cfg2stable cfg2env cfg3 cfg4 cfg5 ...] [--procs P]
 
 Files (tests/golden/):
   filter_cfg1.npz     Benes--Bernoulli N = 7, T = 100, B = 3, raw / central / scaled, TME-3 (BASELINE configs[0])
   filter_cfg2.npz     Benes--Bernoulli N = 15, TME-3, central and scaled: the first 64 replicates x first 300 steps of
                       the benchmark batch (synth seed 100, B = 4096, T = 1000): NLL, means, variances / scales for
                       every step, all 2N moments at every 10th step, first-NaN step (BASELINE configs[1], slice)
+  filter_cfg2stable.npz  the same 64 replicates x 300 steps with stable=True (LDL^T completion), central
   filter_cfg2env.npz  the same batch, first 1024 replicates x all 1000 steps, central: NLL, first-NaN step, means and
                       variances at every 100th step -- the NumPy/LAPACK leg of the three-way envelope test
   filter_cfg3.npz     OU / Gaussian convergence model N in {5, 10, 15, 20, 25}, T = 200, B = 4, central (configs[2])
@@ -110,6 +111,26 @@ def cfg2(procs):
     return out
 
 
+def _cfg2_stable_one(args):
+    b, T = args
+    ora, opmf, oic, ys = _G['ora'], _G['opmf'], _G['oic'], _G['ys']
+    m, means, nell = o.moment_filter_cms(ora[1], ora[3], opmf, oic.cms, oic.mean, ys[b, :T], stable=True)
+    return m, means, m[:, 2].copy(), nell
+
+
+def cfg2stable(procs):
+    """The 64 replicates of filter_cfg2.npz with stable=True (LDL^T completion, mfs/utils.py:525-538), central mode."""
+    N = _cfg2_setup()
+    B, T, every = 64, 300, 10
+    res = _pool_map(_cfg2_stable_one, [(b, T) for b in range(B)], procs)
+    return {'N': N, 'T': T, 'B': B, 'seed': 100, 'batch_B': 4096, 'batch_T': 1000, 'tme_order': 3,
+            'moment_steps': np.arange(every - 1, T, every), 'ys_bits': np.packbits(_G['ys'][:B, :T].astype(np.uint8), axis=1),
+            'central_moments': np.stack([r[0][every - 1::every] for r in res]),
+            'central_means': np.stack([r[1] for r in res]), 'central_variances': np.stack([r[2] for r in res]),
+            'central_nell': np.array([r[3] for r in res]),
+            'central_first_nan': np.array([first_nan_of(np.column_stack([r[1], r[0]])) for r in res], dtype=np.int32)}
+
+
 def cfg2env(procs):
     N = _cfg2_setup()
     B, T, every = 1024, 1000, 100
@@ -192,7 +213,7 @@ def cfg5(procs):
             'normal2_means': np.stack([r[1] for r in resn]), 'normal2_nell': np.array([r[2] for r in resn])}
 
 
-CONFIGS = {'cfg1': cfg1, 'cfg2': cfg2, 'cfg2env': cfg2env, 'cfg3': cfg3, 'cfg4': cfg4, 'cfg5': cfg5}
+CONFIGS = {'cfg1': cfg1, 'cfg2': cfg2, 'cfg2stable': cfg2stable, 'cfg2env': cfg2env, 'cfg3': cfg3, 'cfg4': cfg4, 'cfg5': cfg5}
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
