@@ -106,6 +106,9 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-end-to-end', action='store_true', help='skip the reference-shaped host API timing')
     p.add_argument('--no-other-workloads', action='store_true', help='skip the short runs of configs 3 / 4 / 5')
+    p.add_argument('--extra-kernels', action='store_true',
+                   help='run only the gradient and characteristic-function entries of `other_workloads` and print them '
+                        '(what tools/profile.sh puts under rocprofv3 for those two kernels)')
     p.add_argument('--allow-host-gather', action='store_true',
                    help='multi-rank: exit 0 even if the NLL all-gather fell back from RCCL to the host route')
     p.add_argument('--dry-run', action='store_true',
@@ -534,6 +537,11 @@ def main():
     if args.dry_run:
         dry_run(args, comm, rank, world)
     _lib.check(L.mfs_set_device(device))
+    if args.extra_kernels:
+        if rank == 0:
+            print(json.dumps(extra_kernels(device)), flush=True)
+        comm.close(0)
+        sys.exit(0)
     want_moments = not args.no_moments
 
     w = make_workload(args.workload, args.B, args.T, rank, device)
@@ -628,6 +636,64 @@ def end_to_end(w):
         'output_bytes': int(w.B * w.T * (w.z + 1) * 8), 'pool': stats}}
 
 
+def extra_kernels(device):
+    """The two kernels beside the filters through their host-pointer entry points -- wall time of
+    the call (trace, H2D, kernel, D2H), median of three after a warm-up: PCIe-inclusive, never `value`.  Their kernel-only
+    times are in the rocprofv3 traces under profiles/."""
+    from mfs_amd import synth, estimation
+    from mfs_amd.one_dim import moments, ss_models
+    out = {}
+    try:   # forward-mode NLL gradient: well--Poisson N = 7, TME-normal-2, P = 2, one theta point per replicate (config 4's model)
+        N, T, B = 7, 1000, 16384
+        dt, _, _, ic, drift, dispersion, _, pmf, _ = ss_models.well_poisson(3., N)
+        rng = np.random.default_rng(7)
+        th = rng.uniform(0.5, 6., size=(B, 2))
+        ys, _ = synth.well_poisson_batch(256, T, p1=3., p2=3., dt=dt, seed=100, substeps=2)
+        ys = np.ascontiguousarray(np.tile(ys, (B // 256, 1)))
+
+        def model(P):
+            _, c, _, mu, _ = moments.sde_cond_moments_tme_normal(lambda x: drift(x, P[:, 0]), dispersion, dt, 2, N)
+            return c, mu, (lambda y, x: pmf(y, x, P[:, 1]))
+
+        def call():
+            return estimation.nell_and_grad_forward(model, th, ic.cms, ic.mean, ys)
+        call()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            nell, grad = call()
+            ts.append(time.perf_counter() - t0)
+        ms = float(np.median(ts)) * 1e3
+        out['gradient_N7_P2'] = {'workload': 'well_poisson_N7_T1000 central tme_normal_2, d NLL / d theta in the time loop, P = 2',
+                                 'kernel': 'mfs::filter1d_grad_kernel', 'filters': B, 'T': T, 'call_ms': ms,
+                                 'filters_per_s': B / (ms * 1e-3), 'filter_steps_per_s': B * T / (ms * 1e-3),
+                                 'finite': int(np.isfinite(nell).sum()), 'timing': 'wall time of the host-pointer call'}
+    except Exception as e:   # noqa: BLE001
+        out['gradient_N7_P2'] = {'error': repr(e)}
+    try:   # characteristic function of the filtering distributions (post_processing_mf.py:37-60): N = 15, 2000 z points
+        N, count, nz = 15, 8192, 2000
+        rng = np.random.default_rng(8)
+        mus, vs = rng.normal(scale=0.5, size=count), rng.uniform(0.3, 1.2, size=count)
+        from mfs_amd.one_dim.moments import central_moment_of_normal
+        base = np.array([central_moment_of_normal(1., p) for p in range(2 * N)])
+        cms = base[None, :] * np.sqrt(vs)[:, None] ** np.arange(2 * N)[None, :]
+        zs = np.linspace(-2., 2., nz)
+        moments.characteristic_fn(zs, cms[:64], mus[:64])
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            cf = moments.characteristic_fn(zs, cms, mus)
+            ts.append(time.perf_counter() - t0)
+        ms = float(np.median(ts)) * 1e3
+        out['characteristic_fn_N15'] = {'kernel': 'mfs::cf1d_fast_kernel', 'moment_vectors': count, 'z_points': nz, 'call_ms': ms,
+                                        'vector_z_points_per_s': count * nz / (ms * 1e-3), 'output_bytes': int(cf.nbytes),
+                                        'timing': 'wall time of the host-pointer call (D2H of the complex128 grid included)'}
+        del cf
+    except Exception as e:   # noqa: BLE001
+        out['characteristic_fn_N15'] = {'error': repr(e)}
+    return out
+
+
 def other_workloads(comm, device):
     """Short runs (1 warm-up + 2 timed passes) of the other BASELINE configurations, kernel time from HIP events."""
     out = {}
@@ -646,6 +712,7 @@ def other_workloads(comm, device):
             w.release()
         except Exception as e:   # noqa: BLE001
             out[label] = {'workload': name, 'error': repr(e)}
+    out.update(extra_kernels(device))
     return out
 
 

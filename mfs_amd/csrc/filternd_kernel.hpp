@@ -121,8 +121,7 @@ struct NdTile {
     static constexpr int LD = NP + 1;
     static constexpr int R = S * S;                  // tensor-product nodes
     static constexpr int oMom = 0;
-    static constexpr int oA = (Z + 1) & ~1;          // [NP][LD] G -> R
-    static constexpr int oK = oA + NP * LD;          // [2][NP][LD]
+    static constexpr int oK = (Z + 1) & ~1;          // [2][NP][LD]
     static constexpr int oV = oK + 2 * NP * LD;      // [2][NP][LD]
     static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
     // Normal closures integrate over s^2 eigen-nodes (weights W, coordinates lam) or -- when the integrand's degree allows --
@@ -145,13 +144,19 @@ struct NdTile {
     // (r, item) only, and recomputing it cost ~50 integer instructions per thread per round next to ~30 flops.
     //   KT[r][P * HP + Q] = p1 | p2 << 8 | q1 << 16 | q2 << 24  (u32)
     // (not for Normal closures: their Jacobi is a fallback now -- strided rounds -- and the 10 KB go to the Chebyshev-grid tables)
-    static constexpr bool kTables = (TK != 1) && (2 * HP * HP <= 256) && (2 * S * HP <= 512);
+    // (round 3: off -- Jacobi is a rarely taken fallback on every path now, and the 10 KB of tables cost the third workgroup per CU)
+    static constexpr bool kTables = false;
     static constexpr int oIdxK = oMisc + 8;
     static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
     // bilinear-form path: Krylov tiles, the moment array of the rule and its shifted copy, re-centred coefficients
     static constexpr int NPW = P + kMaxD;                  // powers 0 .. 2N-1 + (D-1)
     static constexpr int MLD = NPW + 1;
     static constexpr int oPK = oIdxK + nIdxK;                // [2][NPW][NP]
+    // free during a front end and during a Jacobi run, the Krylov tiles also serve as: the rows of R+ and 1 / R_jj
+    // ([S + N + 1][S + 1] + [S], default front end), the Gram tile of the LDL^T completion and Jacobi's scratch ([NP][LD])
+    static constexpr int oRp = oPK;
+    static constexpr int oA = oPK;
+    static_assert((S + N + 1) * (S + 1) + S <= 2 * NPW * NP && NP * LD <= 2 * NPW * NP, "front-end tiles alias the Krylov tiles");
     static constexpr int oM = oPK + 2 * NPW * NP;            // [NPW][MLD]
     static constexpr int oM2 = oM + NPW * MLD;               // [NPW][MLD]
     static constexpr int oQs = oM2 + NPW * MLD;              // [kRows][kMaxD * kMaxD] (operator path)
@@ -176,11 +181,7 @@ struct NdTile {
     static constexpr int oFf = oTerms + (kOperator ? (kMaxTermWords + kTermPad + 2) / 2 : 0);   // [P][FFS]
     // gather indices of G, H_0, H_1 as u16 ([3][S][S]), when they fit next to the rest at two workgroups per CU: the
     // per-rule gather then makes no global-memory round trip
-    static constexpr int oGi = oFf + (kOperator ? P * FFS : 0);
-    static constexpr int nGi = (3 * S * S + 3) / 4;
-    static constexpr int nChebGrid = (TK == 1) ? 28 * 28 + 28 : 0;       // (kNcpMax^2 + kNcpMax, laid out after the gather table)
-    static constexpr bool kGatherLds = (oGi + nGi + nChebGrid) * 8 <= 80 * 1024;
-    static constexpr int kDoubles0 = oGi + (kGatherLds ? nGi : 0);
+    static constexpr int kDoubles0 = oFf + (kOperator ? P * FFS : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
     // moment-array tiles (free while a Jacobi runs)
     // Chebyshev-grid rule of a Normal closure: the transform table D[a][p] = (2 - [a = 0]) / NCP cos(pi a (p + 1/2) / NCP), the
@@ -321,6 +322,13 @@ __device__ __forceinline__ void fnma_chain_range(double* acc, const double u, co
     }
 }
 
+// total degree of the multi-index with graded-lex number j (d = 2: block m holds the m + 1 indices m (m + 1) / 2 ...)
+__device__ __host__ constexpr int nd_degree(int j) {
+    int m = 0;
+    while ((m + 1) * (m + 2) / 2 <= j) ++m;
+    return m;
+}
+
 // pair p of round r in the round-robin tournament on NP players
 template <int NP>
 __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p, int& q) {
@@ -328,8 +336,10 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
     else { p = r + P; if (p >= NP - 1) p -= NP - 1; q = r - P; if (q < 0) q += NP - 1; }
 }
 
-// Front end of a rule: gather, Cholesky (or LDL^T completion), both triangular solves, symmetrisation.  Leaves the
-// symmetric K_0, K_1 in their LDS tiles; returns the block-uniform poison flag (a pivot that is not > 0).
+// Front end of a rule (quadratures.py:151-161): G = ms[inds[0]], H_k = ms[inds[1 + k]], R = chol(G), K_k = R^-1 H_k R^-T.
+// Leaves the symmetric K_0, K_1 in their LDS tiles; returns the block-uniform poison flag (a pivot that is not > 0).
+// The index tables are the graded-lex ones of multi_indices.py:185-229 (the host checks that `inds` is that table), so
+// the default path computes the gather arithmetically; stable = 1 (LDL^T completion) keeps the dense LDS-tile form.
 template <int N, int TK>
 __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
     using L = NdTile<N, TK>;
@@ -341,108 +351,163 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
     double* flags = Sm + L::oMisc + 4;
 
     ND_STAMP_BEGIN;
-    // -- gather (quadratures.py:151-152); pad rows / columns are zero
-    for (int e = tid; e < NP * NP; e += nthr) {
-        const int i = e / NP, j = e - i * NP;
-        const bool in = (i < S) && (j < S);
-        const int o = in ? i * S + j : 0;
-        int g0, g1, g2;
-        if constexpr (L::kGatherLds) {
-            const unsigned short* gi = reinterpret_cast<const unsigned short*>(Sm + L::oGi);
-            g0 = gi[o]; g1 = gi[S * S + o]; g2 = gi[2 * S * S + o];
-        } else {
-            g0 = inds[o]; g1 = inds[S * S + o]; g2 = inds[2 * S * S + o];
-        }
-        const double v0 = mom[g0], v1 = mom[g1], v2 = mom[g2];
-        A[i * LD + j] = in ? v0 : 0.0;
-        K[i * LD + j] = in ? v1 : 0.0;
-        K[NP * LD + i * LD + j] = in ? v2 : 0.0;
-    }
     if (tid == 0) flags[0] = 0.0;
-    __syncthreads();
+    if (stable) {
+        // -- gather (quadratures.py:151-152) for the LDL^T completion below; pad rows / columns are zero
+        for (int e = tid; e < NP * NP; e += nthr) {
+            const int i = e / NP, j = e - i * NP;
+            const bool in = (i < S) && (j < S);
+            const int o = in ? i * S + j : 0;
+            const double v0 = mom[inds[o]], v1 = mom[inds[S * S + o]], v2 = mom[inds[2 * S * S + o]];
+            A[i * LD + j] = in ? v0 : 0.0;
+            K[i * LD + j] = in ? v1 : 0.0;
+            K[NP * LD + i * LD + j] = in ? v2 : 0.0;
+        }
+        __syncthreads();
+    }
 
     ND_STAMP(0);
     // -- Cholesky (quadratures.py:154) or LDL^T completion (mfs/utils.py:495-538)
     if (!stable) {
-        // Register-resident front end on ONE wave, no barriers: lane i (< S) owns row i of G -> L; lane c (< 2S) owns
-        // column c of [H_0 | H_1].  Column step j needs L[j][k] in every lane, twice: for the Cholesky dot products
-        // and for the forward substitution X = R^-1 [H_0 | H_1] (quadratures.py:156-161, inner solve) fused into
-        // the same sweep.  As soon as column k of L is final, gfx950's lane swaps (v_permlane16_swap / 32_swap on
-        // (v, copy of v)) spread DPP row 0 and DPP row 1 of it over all four rows of the wave, once; every later use
-        // is then the row_newbcast operand of the multiply-add itself (one instruction per term instead of two
-        // v_readlane + a multiply-add).  The outer solve K^T = R^-1 X^T reuses them after a transpose through the K tiles.
+        // Front end on ONE wave, in registers.  Two facts about monomial Gram matrices carry it (the N-D form of what the
+        // 1-D kernel does with its Hankel matrix):
+        //   * H_k is G "shifted by e_k": H_k[i][j] = m[alpha_i + e_k + alpha_j] = G+[sigma_k(i)][j] with G+ the Gram matrix
+        //     extended by the N + 1 monomials of degree N (rows only: degree <= 2N - 1 is all it needs) and sigma_k(i) the
+        //     index of alpha_i + e_k.  With G = R R^T and R+ = [R; W], W R^T = the extension rows, this is H_k = P_k R+ R^T,
+        //     hence   K_k = R^-1 H_k R^-T = R^-1 (P_k R+)  --  ONE triangular solve, and no gather of H_0, H_1 at all.
+        //   * K_k is the matrix of "multiply by x_k" in the orthonormal polynomials, graded by degree: block tridiagonal
+        //     (blocks of 1, 2, ..., N).  Outside that band the reference's dense K_k holds rounding noise only (2e-15 of
+        //     max |K| on config 5; dropping it moves no moment by more than 5e-10 over 200 steps, the same as any two dense
+        //     implementations differ).  Column j of K_k (degree c) then needs the rows of degree c - 1 and c only:
+        //         K[c-1, j] = R[c-1,c-1]^-1 (P_k R+)[c-1, j],     K[c, j] = R[c,c]^-1 ((P_k R+)[c, j] - R[c,c-1] K[c-1, j]),
+        //     two forward substitutions of at most N - 1 and N unknowns; the blocks below the diagonal are the transposes.
+        // Lane r < S + N + 1 owns row r of G+.  The elimination is right-looking and square-root free (L D L^T): as soon
+        // as column j is final its UNSCALED entries are spread over the four DPP rows by lane swaps while 1 / d_j forms
+        // (the two chains run side by side), the lane's own factor u_rj / d_j multiplies them in fused DPP multiply-adds,
+        // and 1 / sqrt(d_j) -- needed only for the rows of R+ that go to LDS -- stays off the chain.
+        constexpr int SP = S + N + 1;                 // rows of G+
+        constexpr int LDR = S + 1;
+        static_assert(SP <= 64 && S <= 32, "rows of G+ in one wave, columns of L in DPP rows 0 and 1");
+        double* Rp = Sm + L::oRp;                     // [SP][LDR] rows of R+ (the Krylov tiles are free during a front end)
+        double* rinv = Rp + SP * LDR;                 // [S] 1 / R_jj
         if (tid < 64) {
-            const int li = (tid < S) ? tid : S - 1;
-            const int hc = (tid < 2 * S) ? tid : 0, hm = hc / S, hj = hc - hm * S;
-            static_assert(S <= 32, "rows of L live in DPP rows 0 and 1");
-            constexpr int S0 = (S < 16) ? S : 16;     // columns whose entries are needed from DPP row 0 (rows j < 16)
-            // When 3 S <= 64 the rows of G (lanes 0 .. S-1) and the columns of [H_0 | H_1] (lanes S .. 3S-1) share ONE
-            // register array: elimination and forward substitution are the same instruction -- v[c] -= v[j] L[c][j] -- on
-            // different lanes, so one stream of fused DPP multiply-adds serves both (a third fewer than two streams).
-            constexpr bool kMerged = (3 * S <= 64);
-            const int xc_lane = kMerged ? ((tid >= S && tid < 3 * S) ? tid - S : 0) : hc;     // which column of [H_0 | H_1] this lane eliminates
-            const int xm = xc_lane / S, xj = xc_lane - xm * S;
-            const bool is_row = tid < S;
-            double Lr[S], xc[kMerged ? 1 : S];
-            double rinvs[S];                          // 1 / L_jj: every lane computes the same numbers, so they simply stay in registers
-                                                      // (parking them in LDS cost a branch, a scalar load and a store per column)
-            double D0[S0], D1[(S > 16) ? S : 1];      // column k of L: DPP row 0 / DPP row 1 of it in all four rows
-            static_for<0, S>([&](auto Jc) {
-                const double gv = A[li * LD + Jc], hv = K[xm * NP * LD + Jc * LD + xj];
-                if constexpr (kMerged) Lr[Jc] = is_row ? gv : hv;
-                else { Lr[Jc] = gv; xc[Jc] = hv; }
+            const int r = (tid < SP) ? tid : SP - 1;
+            int mr = 0;
+            while ((mr + 1) * (mr + 2) / 2 <= r) ++mr;              // degree of alpha_r, position in its block
+            const int ur = r - mr * (mr + 1) / 2;
+            double v[S];
+            static_for<0, S>([&](auto Jc) {                          // G+[r][j] = m[alpha_r + alpha_j], graded-lex index
+                constexpr int j = Jc;
+                constexpr int mj = nd_degree(j), uj = j - mj * (mj + 1) / 2;
+                const int M = mr + mj;
+                v[j] = mom[M * (M + 1) / 2 + ur + uj];
             });
+            __builtin_amdgcn_sched_barrier(0);
             bool bad = false;
-            // right-looking: a final column is subtracted from every later column at once (blocks of eight fused DPP
-            // multiply-adds behind one hazard nop, independent accumulators) -- each column still receives its terms in
-            // the order k = 0, 1, ..., so the numbers are those of the column-by-column form
-            constexpr int loE = (S < 16) ? S : 16;
+            constexpr int S0 = (S < 16) ? S : 16;
             static_for<0, S>([&](auto Jc) {
                 constexpr int j = Jc;
-                const double s = Lr[j];
-                const double pj = bcast<64, j>(s);
-                bad |= !(pj > 0.0);
-                const double rinv = rsq_nr(pj);
-                rinvs[j] = rinv;
-                Lr[j] = s * rinv;       // row j itself gets sqrt(piv) = piv * rinv
-                if constexpr (!kMerged) xc[j] = xc[j] * rinv;
-                if constexpr (j + 1 < S) {   // column j is final: spread its two DPP rows over the wave
-                    double ev, od, lo, up;
-                    row_dup(Lr[j], ev, od);
-                    if constexpr (j < S0) { half_dup(ev, lo, up); D0[j] = lo; }
-                    if constexpr (S > 16) { half_dup(od, lo, up); D1[j] = lo; }
-                    if constexpr (j + 1 < loE) {
-                        fnma_chain_range<j + 1, loE, 0>(Lr, Lr[j], D0[j]);
-                        if constexpr (!kMerged) fnma_chain_range<j + 1, loE, 0>(xc, xc[j], D0[j]);
-                    }
+                const double uj = v[j];
+                const double dj = bcast<64, j>(uj);
+                bad |= !(dj > 0.0);
+                if constexpr (j + 1 < S) {   // the unscaled column to all four DPP rows (independent of the reciprocal below)
+                    double ev, od, lo0 = 0.0, lo1 = 0.0, up;
+                    row_dup(uj, ev, od);
+                    if constexpr (j + 1 < S0) half_dup(ev, lo0, up);
+                    if constexpr (S > 16) half_dup(od, lo1, up);
+                    // 1 / d_j: seed + two Newton steps, the second folded into the product (as in the 1-D kernel)
+                    const double y0 = __builtin_amdgcn_rcp(dj);
+                    const double y1 = fma(fma(-dj, y0, 1.0), y0, y0);
+                    const double delta = fma(-dj, y1, 1.0);
+                    const double ty = uj * y1;
+                    const double t = fma(ty, delta, ty);               // u_rj / d_j = L_rj
+                    if constexpr (j + 1 < S0) fnma_chain_range<j + 1, S0, 0>(v, t, lo0);
                     if constexpr (S > 16) {
                         constexpr int hi0 = (j + 1 > 16) ? j + 1 : 16;
-                        fnma_chain_range<hi0, S, 16>(Lr, Lr[j], D1[j]);
-                        if constexpr (!kMerged) fnma_chain_range<hi0, S, 16>(xc, xc[j], D1[j]);
+                        fnma_chain_range<hi0, S, 16>(v, t, lo1);
                     }
                 }
+                const double rs = rsq_nr(dj);                         // off the chain: R+[r][j] = u_rj / sqrt(d_j)
+                Rp[r * LDR + j] = uj * rs;
+                if (tid == 0) rinv[j] = rs;
             });
             if (tid == 0 && bad) flags[0] = 1.0;
-            // transpose X through the K tiles: column xj of X_m -> K_m[:, xj]
-            static_for<0, S>([&](auto Jc) {
-                if constexpr (kMerged) { if (tid >= S && tid < 3 * S) K[xm * NP * LD + Jc * LD + xj] = Lr[Jc]; }
-                else { if (tid < 2 * S) K[xm * NP * LD + Jc * LD + xj] = xc[Jc]; }
-            });
             wave_sync();
-            // row hj of X_m is column hj of X_m^T: forward-substitute it, K_m[hj][:] = (R^-1 X_m^T)[:, hj]
-            double yr[S];
-            static_for<0, S>([&](auto Jc) { yr[Jc] = K[hm * NP * LD + hj * LD + Jc]; });
-            static_for<0, S>([&](auto Ic) {
-                constexpr int i = Ic;
-                yr[i] = yr[i] * rinvs[i];
-                if constexpr (i + 1 < loE) fnma_chain_range<i + 1, loE, 0>(yr, yr[i], D0[i]);
-                if constexpr (S > 16 && i + 1 < S) {
-                    constexpr int hi0 = (i + 1 > 16) ? i + 1 : 16;
-                    fnma_chain_range<hi0, S, 16>(yr, yr[i], D1[i]);
-                }
-            });
+            // ---- the two forward substitutions of column j of K_k; lane t = k S + j
+            if (tid < 2 * S) {
+                const int k = tid / S, j = tid - k * S, dk = (k == 0) ? 1 : 0;
+                int c = 0;
+                while ((c + 1) * (c + 2) / 2 <= j) ++c;
+                const int b0 = c * (c - 1) / 2, b1 = c * (c + 1) / 2, b2 = (c + 1) * (c + 2) / 2;   // first index of degree c - 1, c, c + 1
+                double* Kk = K + k * NP * LD;
+                double x[(N > 1) ? N - 1 : 1], y[N];
+                // every R+ / rinv operand first (fixed trip counts; rows beyond the block are clamped and masked)
+                double rhs1[(N > 1) ? N - 1 : 1], ri1[(N > 1) ? N - 1 : 1], Ra[(N > 1) ? (N - 1) * (N - 2) / 2 + 1 : 1];
+                static_for<0, N - 1>([&](auto Qc) {
+                    constexpr int q = Qc;
+                    const bool in = q < c;
+                    const int row = in ? b1 + q + dk : 0;            // sigma_k(b0 + q)
+                    const double rv = Rp[row * LDR + j];
+                    rhs1[q] = (in && j <= row) ? rv : 0.0;
+                    ri1[q] = rinv[in ? b0 + q : 0];
+                    static_for<0, q>([&](auto Lc) { Ra[q * (q - 1) / 2 + Lc] = in ? Rp[(b0 + q) * LDR + b0 + Lc] : 0.0; });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, N - 1>([&](auto Qc) {
+                    constexpr int q = Qc;
+                    double sacc = rhs1[q];
+                    static_for<0, q>([&](auto Lc) { sacc = fma(-Ra[q * (q - 1) / 2 + Lc], x[Lc], sacc); });
+                    x[q] = sacc * ri1[q];
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                double rhs2[N], ri2[N], Rb[N * (N - 1) + 1], Rc[N * (N - 1) / 2 + 1];
+                static_for<0, N>([&](auto Qc) {
+                    constexpr int q = Qc;
+                    const bool in = q <= c;
+                    const int row = in ? b2 + q + dk : 0;            // sigma_k(b1 + q): degree c + 1 (an extension row when c = N - 1)
+                    rhs2[q] = in ? Rp[row * LDR + j] : 0.0;
+                    ri2[q] = rinv[in ? b1 + q : 0];
+                    static_for<0, N - 1>([&](auto Lc) { Rb[q * (N - 1) + Lc] = (in && Lc < c) ? Rp[(b1 + q) * LDR + b0 + Lc] : 0.0; });
+                    static_for<0, q>([&](auto Lc) { Rc[q * (q - 1) / 2 + Lc] = in ? Rp[(b1 + q) * LDR + b1 + Lc] : 0.0; });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, N>([&](auto Qc) {
+                    constexpr int q = Qc;
+                    double s0 = rhs2[q], s1 = 0.0;
+                    static_for<0, N - 1>([&](auto Lc) { s1 = fma(Rb[q * (N - 1) + Lc], x[Lc], s1); });
+                    static_for<0, q>([&](auto Lc) { s0 = fma(-Rc[q * (q - 1) / 2 + Lc], y[Lc], s0); });
+                    y[q] = (s0 - s1) * ri2[q];
+                });
+                // the band of K_k: rows of degree c - 1 and c in column j, and the mirror of the first
+                static_for<0, N - 1>([&](auto Qc) { if (Qc < c) { Kk[(b0 + Qc) * LD + j] = x[Qc]; Kk[j * LD + b0 + Qc] = x[Qc]; } });
+                static_for<0, N>([&](auto Qc) { if (Qc <= c) Kk[(b1 + Qc) * LD + j] = y[Qc]; });
+            }
             wave_sync();
-            static_for<0, S>([&](auto Jc) { if (tid < 2 * S) K[hm * NP * LD + hj * LD + Jc] = yr[Jc]; });
+            if (tid < 2 * S) {       // (K + K^T) / 2 on the diagonal blocks: the pair (i > j) belongs to column j's lane
+                const int k = tid / S, j = tid - k * S;
+                int c = 0;
+                while ((c + 1) * (c + 2) / 2 <= j) ++c;
+                const int b1 = c * (c + 1) / 2;
+                double* Kk = K + k * NP * LD;
+                static_for<0, N>([&](auto Qc) {
+                    const int i = b1 + Qc;
+                    if (Qc <= c && i > j) {
+                        const double sy = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
+                        Kk[i * LD + j] = sy;
+                        Kk[j * LD + i] = sy;
+                    }
+                });
+            }
+        } else {
+            // meanwhile: zeros outside the band (a Jacobi fallback or a Chebyshev-grid rule may have used the tiles as scratch)
+            for (int e = tid - 64; e < 2 * NP * NP; e += nthr - 64) {
+                const int k = e / (NP * NP), f = e - k * NP * NP, i = f / NP, j = f - i * NP;
+                int di = 0, dj = 0;
+                while ((di + 1) * (di + 2) / 2 <= i) ++di;
+                while ((dj + 1) * (dj + 2) / 2 <= j) ++dj;
+                const bool band = (i < S) && (j < S) && (di - dj <= 1) && (dj - di <= 1);
+                if (!band) K[k * NP * LD + i * LD + j] = 0.0;
+            }
         }
         __syncthreads();
     } else {
@@ -496,19 +561,21 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
     }
 
     ND_STAMP(1);
-    constexpr int NPAIR = S * (S - 1) / 2;
-    for (int e = tid; e < 2 * NPAIR; e += nthr) {     // one (i > j) pair per item: pair f of the strict lower triangle, row by row
-        double* Kk = K + (e / NPAIR) * NP * LD;
-        const int f = e % NPAIR;
-        int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)f)) * 0.5f);
-        i += ((i + 1) * i / 2 <= f) ? 1 : 0;
-        i -= (i * (i - 1) / 2 > f) ? 1 : 0;
-        const int j = f - i * (i - 1) / 2;
-        const double s = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
-        Kk[i * LD + j] = s;
-        Kk[j * LD + i] = s;
+    if (stable) {
+        constexpr int NPAIR = S * (S - 1) / 2;
+        for (int e = tid; e < 2 * NPAIR; e += nthr) {     // one (i > j) pair per item: pair f of the strict lower triangle, row by row
+            double* Kk = K + (e / NPAIR) * NP * LD;
+            const int f = e % NPAIR;
+            int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)f)) * 0.5f);
+            i += ((i + 1) * i / 2 <= f) ? 1 : 0;
+            i -= (i * (i - 1) / 2 > f) ? 1 : 0;
+            const int j = f - i * (i - 1) / 2;
+            const double sy = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
+            Kk[i * LD + j] = sy;
+            Kk[j * LD + i] = sy;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     ND_STAMP(2);
     return flags[0] != 0.0;
@@ -1215,7 +1282,7 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
     __syncthreads();
     // cardinal vectors u_p = sum_a D[a][p] t_a on all threads, into the tiles of G, K_0, K_1, V_0, V_1 (the matrices have done
     // their work for this half-step; the caller drops the warm start of a later Jacobi fallback)
-    double* Uo = Sm + L::oA;             // [2][ncp][NP]
+    double* Uo = Sm + L::oK;             // [2][ncp][NP]: the tiles of K_0, K_1, V_0, V_1
     for (int e = tid; e < 2 * ncp * S; e += 256) {
         const int w = e / (ncp * S), f = e - w * ncp * S, pp = f / S, r = f - pp * S;
         const double* tw = U + w * ncp * NP + r;
@@ -1314,10 +1381,6 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         if (tid == 0) Sm[L::oQs + L::kTerms * DD6] = 0.0;
         for (int e = tid; e < P * L::FFS; e += 256) Sm[L::oFf + e] = ffact(e / L::FFS, e % L::FFS) * ((e % L::FFS <= e / L::FFS) ? 1.0 : 0.0);
     }
-    if constexpr (L::kGatherLds) {
-        unsigned short* gi = reinterpret_cast<unsigned short*>(Sm + L::oGi);
-        for (int e = tid; e < 3 * S * S; e += 256) gi[e] = (unsigned short)a.inds[e];
-    }
     if (tid < 8) {
         const double* src = a.lik + (a.lik_batched ? (size_t)b * a.n_factors * 4 : 0);
         Sm[L::oLik + tid] = (tid < a.n_factors * 4) ? src[tid] : 0.0;
@@ -1357,7 +1420,7 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
         }
         const int g = max(1, max(dmu, (dsg + 1) / 2));
         ncp = g * (P - 1) + 1;
-        if (ncp > L::kNcpMax || 2 * ncp > 5 * LD || a.force_eigen) ncp = 0;   // (table size; the cardinal vectors' room)
+        if (ncp > L::kNcpMax || 2 * ncp > 4 * LD || a.force_eigen) ncp = 0;   // (table size; the cardinal vectors' room)
         if (ncp > 0) {
             for (int e = tid; e < ncp * ncp; e += 256) {
                 const int aa = e / ncp, pp = e - aa * ncp;

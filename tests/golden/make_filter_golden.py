@@ -114,8 +114,24 @@ def cfg2(procs):
 def _cfg2_stable_one(args):
     b, T = args
     ora, opmf, oic, ys = _G['ora'], _G['opmf'], _G['oic'], _G['ys']
-    m, means, nell = o.moment_filter_cms(ora[1], ora[3], opmf, oic.cms, oic.mean, ys[b, :T], stable=True)
-    return m, means, m[:, 2].copy(), nell
+    # which rule (2 per step) is the first whose LDL^T has a pivot that is not > 0: from there on the run is no longer the
+    # plain filter (the reference's explicit LDL^T loop rounds differently from LAPACK's potrf, so this is not always the
+    # step at which the plain oracle run poisons)
+    calls, first = [0], [-1]
+    ldl0 = o.ldl
+
+    def spy(mat):
+        l, d = ldl0(mat)
+        if first[0] < 0 and not np.all(d > 0):
+            first[0] = calls[0]
+        calls[0] += 1
+        return l, d
+    o.ldl = spy
+    try:
+        m, means, nell = o.moment_filter_cms(ora[1], ora[3], opmf, oic.cms, oic.mean, ys[b, :T], stable=True)
+    finally:
+        o.ldl = ldl0
+    return m, means, m[:, 2].copy(), nell, (first[0] // 2 if first[0] >= 0 else -1)
 
 
 def cfg2stable(procs):
@@ -128,6 +144,7 @@ def cfg2stable(procs):
             'central_moments': np.stack([r[0][every - 1::every] for r in res]),
             'central_means': np.stack([r[1] for r in res]), 'central_variances': np.stack([r[2] for r in res]),
             'central_nell': np.array([r[3] for r in res]),
+            'central_first_completion': np.array([r[4] for r in res], dtype=np.int32),   # step of the first completed rule, -1: none
             'central_first_nan': np.array([first_nan_of(np.column_stack([r[1], r[0]])) for r in res], dtype=np.int32)}
 
 

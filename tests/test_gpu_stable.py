@@ -151,8 +151,9 @@ def test_config2_stable_runs_the_fast_kernel_and_matches_the_oracle_golden():
     sm, smean, snell, sfn = filtering.moment_filter_cms(f[1], f[3], pmf, ic.cms, ic.mean, ys, stable=True, return_first_nan=True)
     pm, pmean, pnell, pfn = filtering.moment_filter_cms(f[1], f[3], pmf, ic.cms, ic.mean, ys, stable=False, return_first_nan=True)
     first = np.where(pfn >= 0, pfn, T)             # the step of a replicate's first completed rule = where the plain run poisons
-    gp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_cfg2.npz'))['central_first_nan']
-    ofirst = np.where(gp >= 0, gp, T)              # ... and where the oracle's plain run does (its own rounding: earlier for some)
+    gp = g['central_first_completion']
+    ofirst = np.where(gp >= 0, gp, T)              # ... and the step of the ORACLE's first completed rule (its own rounding: the
+                                                   # reference's explicit LDL^T loop, not LAPACK's potrf, decides there)
     gvar, gmean, gnell, gfn = g['central_variances'], g['central_means'], g['central_nell'], g['central_first_nan']
     clean = late = 0
     worst_var, worst_mean = [], []
