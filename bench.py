@@ -699,7 +699,7 @@ def other_workloads(comm, device):
     out = {}
     for name, B, label in OTHER_WORKLOADS:
         try:
-            w = make_workload(name, B, 0, 0, device, fast_data=True)
+            w = make_workload(name, B, 0, 0, device, fast_data=(label != 'config2_scaled'))   # (the exact-arithmetic fixture holds the default data)
             res = timed_passes(w, comm, 2, 1, True, 0)
             s = summarise(w, res, 2, 1, True)
             out[label] = {'workload': name, 'replicates': w.B, 'T': w.T, 'N': w.N, 'kernel_ms': s['kernel_ms'],
@@ -707,6 +707,11 @@ def other_workloads(comm, device):
                           'live_fraction': s['live_fraction'], 'replicates_alive_at_T': int(res['alive']),
                           'unit': 'filter-steps/s', 'kernel': w.kernel,
                           'hbm_gbs_algorithmic': s['hbm_gbs']}
+            if label == 'config2_scaled':   # the scaled representation's worst replicates against exact arithmetic (device side)
+                t = exact_tails_errors(w, 'scaled', w.d_mom.to_array((w.B, w.T, 2 * w.N)), w.d_means.to_array((w.B, w.T)),
+                                       w.d_scales.to_array((w.B, w.T)), res['nell'])
+                if t:
+                    out[label]['max_rel_err_vs_exact_arithmetic_worst_replicates'] = t
             if label == 'config5_B512':     # the reference-shaped N-D entry point on the same data, host arrays in and out
                 out[label]['end_to_end_ms'] = end_to_end(w)['end_to_end_ms']
             w.release()
@@ -842,13 +847,13 @@ def cpu_baseline(args, w, res):
     if mode == 'scaled' and w.d_scales is not None:
         err['scale'] = parity.quantity_errors(w.d_scales.to_array((w.B, T))[:nb], cscales)
     out['max_rel_err_vs_device'] = err
-    exact = exact_arithmetic_errors(w, cm, cmeans, cnell, nb)
+    exact = exact_arithmetic_errors(w, cm, cmeans, cnell, nb, dev_nell)
     if exact:
         out['max_rel_err_vs_exact_arithmetic'] = exact
     return out
 
 
-def exact_arithmetic_errors(w, cm, cmeans, cnell, nb):
+def exact_arithmetic_errors(w, cm, cmeans, cnell, nb, dev_nell=None):
     """Device and C port against the 80-digit trajectories of tests/golden/filter_cfg2_exact_T1000.npz (the reference's
     algorithm without rounding, oracle/exact_mp.py) on the replicates the fixture holds -- the benchmark batch's first 8.
     Two fp64 implementations can only be compared with each other up to their own errors; this is each one's distance from
@@ -874,8 +879,48 @@ def exact_arithmetic_errors(w, cm, cmeans, cnell, nb):
                     'moments_all_orders': parity.quantity_errors(mom[:, steps], e['central_moments'], floor),
                     'moments_by_order_max': parity.moment_errors_by_order(mom[:, steps], e['central_moments']),
                     'first_non_finite_step': [int(v) for v in parity.first_nan_steps(means[..., None], T)]}
-    return {'fixture': 'tests/golden/filter_cfg2_exact_T1000.npz (80-digit mpmath, 8 replicates x 1000 steps)',
-            'device': score(dm, dmeans), 'c_port': score(cm[:B], cmeans[:B])}
+    out = {'fixture': 'tests/golden/filter_cfg2_exact_T1000.npz (80-digit mpmath, 8 replicates x 1000 steps)',
+           'device': score(dm, dmeans), 'c_port': score(cm[:B], cmeans[:B])}
+    tails = exact_tails_errors(w, 'central', w.d_mom.to_array((w.B, T, 2 * w.N)), w.d_means.to_array((w.B, T)), None, dev_nell,
+                               (cm, cmeans, None, cnell) if nb >= w.B else None)
+    if tails:
+        out['worst_replicates'] = tails
+    return out
+
+
+def exact_tails_errors(w, mode, dm, dmeans, dscales, dnell, cpu=None):
+    """The replicates that set `max_rel_err_vs_device` (largest variance / scale, NLL, mean deviation and first-NaN gap
+    between the device and the C port over the whole 4096 x 1000 batch: tools/select_tails.py) against their exact-arithmetic
+    trajectories, tests/golden/filter_cfg2_exact_tails.npz (oracle/exact_mp.py at 200 / 500 digits): each side's own distance
+    from the truth on exactly the replicates where the two disagree most -- which attributes the maxima to a side."""
+    from oracle import parity
+    path = os.path.join(ROOT, 'tests', 'golden', 'filter_cfg2_exact_tails.npz')
+    if not os.path.exists(path) or not w.full_size or w.model != 'benes' or w.N != 15 or w.transition != 'tme_3':
+        return None
+    e = np.load(path)
+    idx, T = e[f'{mode}_idx'], int(e['T'])
+    if T != w.T or idx.max() >= w.B or not np.array_equal(np.packbits(w.ys[idx].astype(np.uint8), axis=1), e[f'{mode}_ys_bits']):
+        return None
+
+    def one(m, means, second, nell):
+        sc = parity.score_against_exact_tails(e, mode, m, means, second, nell)
+        first = parity.first_nan_steps(means[..., None], T)
+        hor = np.where(e[f'{mode}_exact_first_nan'] >= 0, e[f'{mode}_exact_first_nan'], T)
+        return {'max': sc['max'], 'replicates_over_1e-6': sc['replicates_over_1e-6'],
+                'finite_up_to_the_exact_horizon': int(np.sum(first >= hor)), 'filter_steps_compared': int(sc['finite_steps'].sum())}
+    second = dm[idx][..., 2] if mode == 'central' else dscales[idx]
+    nd = dnell[idx] if dnell is not None else np.full(len(idx), np.nan)
+    out = {'fixture': 'tests/golden/filter_cfg2_exact_tails.npz: the %d replicates of this batch with the largest device-vs-C-port '
+                      'deviations (8 by variance / scale, 8 by NLL, 4 by mean, the rest by first-NaN gap), exact arithmetic at '
+                      '200 / 500 digits over T = 1000 or up to the algorithm\'s own loss of positive definiteness' % len(idx),
+           'mode': mode, 'replicates': int(len(idx)), 'device': one(dm[idx], dmeans[idx], second, nd)}
+    if cpu is not None:
+        cm, cmeans, cscales, cnell = cpu
+        out['c_port'] = one(cm[idx], cmeans[idx], cm[idx][..., 2] if mode == 'central' else cscales[idx], cnell[idx])
+        out['attribution'] = ('maxima of max_rel_err_vs_device = the C port\'s distance from exact arithmetic'
+                              if out['c_port']['max']['variance' if mode == 'central' else 'scale'] >
+                              10 * out['device']['max']['variance' if mode == 'central' else 'scale'] else 'see both sides')
+    return out
 
 
 if __name__ == '__main__':

@@ -388,8 +388,8 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
         constexpr int SP = S + N + 1;                 // rows of G+
         constexpr int LDR = S + 1;
         static_assert(SP <= 64 && S <= 32, "rows of G+ in one wave, columns of L in DPP rows 0 and 1");
-        double* Rp = Sm + L::oRp;                     // [SP][LDR] rows of R+ (the Krylov tiles are free during a front end)
-        double* rinv = Rp + SP * LDR;                 // [S] 1 / R_jj
+        double* Lp = Sm + L::oRp;                     // [SP][LDR] rows of the unit lower factor L+ (the Krylov tiles are free during a front end)
+        double* sdv = Lp + SP * LDR;                  // [S] sqrt(d_j), then [S] 1 / sqrt(d_j)
         if (tid < 64) {
             const int r = (tid < SP) ? tid : SP - 1;
             int mr = 0;
@@ -405,99 +405,122 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
             __builtin_amdgcn_sched_barrier(0);
             bool bad = false;
             constexpr int S0 = (S < 16) ? S : 16;
+            constexpr bool kFourRows = SP > 32;       // rows of G+ beyond lane 31 (N = 7): the copies must reach DPP rows 2, 3 too
+            double dmine = 1.0;                       // d_r of this lane's own row (r < S)
+            double tl[S];                             // L_rj: stored together after the loop (one address register, live once)
             static_for<0, S>([&](auto Jc) {
                 constexpr int j = Jc;
                 const double uj = v[j];
                 const double dj = bcast<64, j>(uj);
                 bad |= !(dj > 0.0);
-                if constexpr (j + 1 < S) {   // the unscaled column to all four DPP rows (independent of the reciprocal below)
-                    double ev, od, lo0 = 0.0, lo1 = 0.0, up;
+                dmine = (r == j) ? uj : dmine;
+                // 1 / d_j: seed + two Newton steps, the second folded into the product (as in the 1-D kernel)
+                const double y0 = __builtin_amdgcn_rcp(dj);
+                const double y1 = fma(fma(-dj, y0, 1.0), y0, y0);
+                const double delta = fma(-dj, y1, 1.0);
+                const double ty = uj * y1;
+                const double t = fma(ty, delta, ty);                   // u_rj / d_j = L_rj
+                tl[j] = t;
+                if constexpr (j + 1 < S) {   // the unscaled column to the DPP rows that hold rows of G+ (independent of the reciprocal)
+                    double ev, od, lo0, lo1, up;
                     row_dup(uj, ev, od);
-                    if constexpr (j + 1 < S0) half_dup(ev, lo0, up);
-                    if constexpr (S > 16) half_dup(od, lo1, up);
-                    // 1 / d_j: seed + two Newton steps, the second folded into the product (as in the 1-D kernel)
-                    const double y0 = __builtin_amdgcn_rcp(dj);
-                    const double y1 = fma(fma(-dj, y0, 1.0), y0, y0);
-                    const double delta = fma(-dj, y1, 1.0);
-                    const double ty = uj * y1;
-                    const double t = fma(ty, delta, ty);               // u_rj / d_j = L_rj
+                    lo0 = ev; lo1 = od;
+                    if constexpr (kFourRows) {
+                        if constexpr (j + 1 < S0) half_dup(ev, lo0, up);
+                        if constexpr (S > 16) half_dup(od, lo1, up);
+                    }
                     if constexpr (j + 1 < S0) fnma_chain_range<j + 1, S0, 0>(v, t, lo0);
                     if constexpr (S > 16) {
                         constexpr int hi0 = (j + 1 > 16) ? j + 1 : 16;
                         fnma_chain_range<hi0, S, 16>(v, t, lo1);
                     }
                 }
-                const double rs = rsq_nr(dj);                         // off the chain: R+[r][j] = u_rj / sqrt(d_j)
-                Rp[r * LDR + j] = uj * rs;
-                if (tid == 0) rinv[j] = rs;
             });
             if (tid == 0 && bad) flags[0] = 1.0;
+            if (tid < SP) static_for<0, S>([&](auto Jc) { Lp[r * LDR + Jc] = tl[Jc]; });      // (the spare lanes hold garbage)
+            {   // sqrt(d_r), 1 / sqrt(d_r): one per lane, in parallel
+                const double rsd = rsq_nr(dmine);
+                if (tid < S) { sdv[tid] = dmine * rsd; sdv[S + tid] = rsd; }
+            }
             wave_sync();
-            // ---- the two forward substitutions of column j of K_k; lane t = k S + j
+            ND_STAMP(21);
+            // ---- column j of K_k = D^-1/2 T D^1/2, T = L^-1 (P_k L+): two UNIT lower forward substitutions; lane t = k S + j.
+            //      Every operand sits at (a per-lane base) + (a compile-time offset) in the tile of L+; rows beyond the lane's
+            //      blocks are read too (finite entries of the same tile) and their unknowns forced to zero instead.
             if (tid < 2 * S) {
                 const int k = tid / S, j = tid - k * S, dk = (k == 0) ? 1 : 0;
                 int c = 0;
                 while ((c + 1) * (c + 2) / 2 <= j) ++c;
                 const int b0 = c * (c - 1) / 2, b1 = c * (c + 1) / 2, b2 = (c + 1) * (c + 2) / 2;   // first index of degree c - 1, c, c + 1
-                double* Kk = K + k * NP * LD;
+                const int uj = j - b1;
+                const double* pa = Lp + b0 * LDR + b0;            // L[c-1, c-1]
+                const double* pr1 = Lp + (b1 + dk) * LDR + j;     // (P_k L+)[c-1 rows, j]
+                const double* pb = Lp + b1 * LDR + b0;            // L[c, c-1]
+                const double* pc = Lp + b1 * LDR + b1;            // L[c, c]
+                const double* pr2 = Lp + (b2 + dk) * LDR + j;     // (P_k L+)[c rows, j]
+                const double sdj = sdv[j];
                 double x[(N > 1) ? N - 1 : 1], y[N];
-                // every R+ / rinv operand first (fixed trip counts; rows beyond the block are clamped and masked)
-                double rhs1[(N > 1) ? N - 1 : 1], ri1[(N > 1) ? N - 1 : 1], Ra[(N > 1) ? (N - 1) * (N - 2) / 2 + 1 : 1];
+                double rhs1[(N > 1) ? N - 1 : 1], Ra[(N > 1) ? (N - 1) * (N - 2) / 2 + 1 : 1];
                 static_for<0, N - 1>([&](auto Qc) {
                     constexpr int q = Qc;
-                    const bool in = q < c;
-                    const int row = in ? b1 + q + dk : 0;            // sigma_k(b0 + q)
-                    const double rv = Rp[row * LDR + j];
-                    rhs1[q] = (in && j <= row) ? rv : 0.0;
-                    ri1[q] = rinv[in ? b0 + q : 0];
-                    static_for<0, q>([&](auto Lc) { Ra[q * (q - 1) / 2 + Lc] = in ? Rp[(b0 + q) * LDR + b0 + Lc] : 0.0; });
+                    rhs1[q] = pr1[q * LDR];
+                    static_for<0, q>([&](auto Lc) { Ra[q * (q - 1) / 2 + Lc] = pa[q * LDR + Lc]; });
+                });
+                double rs1[(N > 1) ? N - 1 : 1], rs2[N];
+                static_for<0, N>([&](auto Qc) {
+                    constexpr int q = Qc;
+                    rs2[q] = sdv[S + ((q <= c) ? b1 + q : 0)];
+                    if constexpr (q < N - 1) rs1[q] = sdv[S + ((q < c) ? b0 + q : 0)];
                 });
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, N - 1>([&](auto Qc) {
                     constexpr int q = Qc;
-                    double sacc = rhs1[q];
+                    // row sigma_k(b0 + q) = b1 + q + dk of L+ (unit lower): column j is 1 on the diagonal, 0 above it
+                    const int row = b1 + q + dk;
+                    double sacc = (j < row) ? rhs1[q] : ((j == row) ? 1.0 : 0.0);
                     static_for<0, q>([&](auto Lc) { sacc = fma(-Ra[q * (q - 1) / 2 + Lc], x[Lc], sacc); });
-                    x[q] = sacc * ri1[q];
+                    x[q] = (q < c) ? sacc : 0.0;
                 });
-                __builtin_amdgcn_sched_barrier(0);
-                double rhs2[N], ri2[N], Rb[N * (N - 1) + 1], Rc[N * (N - 1) / 2 + 1];
+                // second substitution, its operands in batches of three rows (all of them at once is 57 doubles: spills)
+                constexpr int kRowBatch = 3;
+                static_for<0, (N + kRowBatch - 1) / kRowBatch>([&](auto Bc) {
+                    constexpr int q0 = Bc * kRowBatch, q1 = (q0 + kRowBatch < N) ? q0 + kRowBatch : N;
+                    double rhs2[kRowBatch], Rb[kRowBatch][(N > 1) ? N - 1 : 1], Rc[kRowBatch][N];
+                    static_for<q0, q1>([&](auto Qc) {
+                        constexpr int q = Qc;
+                        rhs2[q - q0] = pr2[q * LDR];
+                        static_for<0, N - 1>([&](auto Lc) { Rb[q - q0][Lc] = pb[q * LDR + Lc]; });
+                        static_for<0, q>([&](auto Lc) { Rc[q - q0][Lc] = pc[q * LDR + Lc]; });
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<q0, q1>([&](auto Qc) {
+                        constexpr int q = Qc;
+                        double s0 = rhs2[q - q0], s1 = 0.0;       // (rows of degree c + 1 lie below column j: always stored entries)
+                        static_for<0, N - 1>([&](auto Lc) { s1 = fma(Rb[q - q0][Lc], x[Lc], s1); });
+                        static_for<0, q>([&](auto Lc) { s0 = fma(-Rc[q - q0][Lc], y[Lc], s0); });
+                        y[q] = (q <= c) ? s0 - s1 : 0.0;
+                    });
+                });
+                // K[i][j] = T[i][j] sqrt(d_j) / sqrt(d_i).  The band of K_k: rows of degree c - 1 in column j and their mirror;
+                // of the diagonal block the entries on and below the diagonal, mirrored (symmetric in exact arithmetic;
+                // quadratures.py:163 averages the two roundings, a difference of the size of the rounding itself)
+                //  (unconditional stores: an entry outside the lane's blocks goes to the pad column of row 0, which nobody
+                //   reads -- a branch per store cost more than the substitutions)
+                const int kOff = L::oK + k * NP * LD, kDummy = kOff + NP;
+                static_for<0, N - 1>([&](auto Qc) {
+                    const bool in = Qc < c;
+                    const double kv = x[Qc] * sdj * rs1[Qc];
+                    Sm[in ? kOff + (b0 + Qc) * LD + j : kDummy] = kv;
+                    Sm[in ? kOff + j * LD + b0 + Qc : kDummy] = kv;
+                });
                 static_for<0, N>([&](auto Qc) {
-                    constexpr int q = Qc;
-                    const bool in = q <= c;
-                    const int row = in ? b2 + q + dk : 0;            // sigma_k(b1 + q): degree c + 1 (an extension row when c = N - 1)
-                    rhs2[q] = in ? Rp[row * LDR + j] : 0.0;
-                    ri2[q] = rinv[in ? b1 + q : 0];
-                    static_for<0, N - 1>([&](auto Lc) { Rb[q * (N - 1) + Lc] = (in && Lc < c) ? Rp[(b1 + q) * LDR + b0 + Lc] : 0.0; });
-                    static_for<0, q>([&](auto Lc) { Rc[q * (q - 1) / 2 + Lc] = in ? Rp[(b1 + q) * LDR + b1 + Lc] : 0.0; });
+                    const bool in = (Qc <= c) && (Qc >= uj);
+                    const double kv = y[Qc] * sdj * rs2[Qc];
+                    Sm[in ? kOff + (b1 + Qc) * LD + j : kDummy] = kv;
+                    Sm[in ? kOff + j * LD + b1 + Qc : kDummy] = kv;
                 });
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, N>([&](auto Qc) {
-                    constexpr int q = Qc;
-                    double s0 = rhs2[q], s1 = 0.0;
-                    static_for<0, N - 1>([&](auto Lc) { s1 = fma(Rb[q * (N - 1) + Lc], x[Lc], s1); });
-                    static_for<0, q>([&](auto Lc) { s0 = fma(-Rc[q * (q - 1) / 2 + Lc], y[Lc], s0); });
-                    y[q] = (s0 - s1) * ri2[q];
-                });
-                // the band of K_k: rows of degree c - 1 and c in column j, and the mirror of the first
-                static_for<0, N - 1>([&](auto Qc) { if (Qc < c) { Kk[(b0 + Qc) * LD + j] = x[Qc]; Kk[j * LD + b0 + Qc] = x[Qc]; } });
-                static_for<0, N>([&](auto Qc) { if (Qc <= c) Kk[(b1 + Qc) * LD + j] = y[Qc]; });
             }
-            wave_sync();
-            if (tid < 2 * S) {       // (K + K^T) / 2 on the diagonal blocks: the pair (i > j) belongs to column j's lane
-                const int k = tid / S, j = tid - k * S;
-                int c = 0;
-                while ((c + 1) * (c + 2) / 2 <= j) ++c;
-                const int b1 = c * (c + 1) / 2;
-                double* Kk = K + k * NP * LD;
-                static_for<0, N>([&](auto Qc) {
-                    const int i = b1 + Qc;
-                    if (Qc <= c && i > j) {
-                        const double sy = 0.5 * (Kk[i * LD + j] + Kk[j * LD + i]);
-                        Kk[i * LD + j] = sy;
-                        Kk[j * LD + i] = sy;
-                    }
-                });
-            }
+            ND_STAMP(22);
         } else {
             // meanwhile: zeros outside the band (a Jacobi fallback or a Chebyshev-grid rule may have used the tiles as scratch)
             for (int e = tid - 64; e < 2 * NP * NP; e += nthr - 64) {

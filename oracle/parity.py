@@ -80,3 +80,46 @@ def first_nan_agreement(fa, fb, T):
     if both_dead.any():
         out['abs_step_difference_p50_p90_p99_when_both_poison'] = [float(v) for v in np.quantile(d[both_dead], [0.5, 0.9, 0.99])]
     return out
+
+
+def score_against_exact_tails(fixture, mode, moments, means, second, nell, T=None):
+    """Distance of one implementation from the exact-arithmetic trajectories of tests/golden/filter_cfg2_exact_tails.npz
+    (the worst replicates of the headline batch, oracle/exact_mp.py at 200 / 500 digits).
+
+    fixture  the loaded .npz;  mode 'central' | 'scaled'
+    moments (R, T, 2N), means (R, T), second (R, T) = variance (central) / scale (scaled), nell (R,) of the fixture's replicates
+    Compared at every step at which the implementation is finite, up to the step where exact arithmetic itself loses positive
+    definiteness (`exact_first_nan`: an event of the algorithm, not of rounding).  Per replicate: the largest error of the mean
+    (in standard deviations), of the variance / scale, of the moments of every order at every 10th step (scaled as
+    `moment_floor`), and of the final NLL where both reach T.  Returns {'per_replicate': (R, 4) array, 'max': {...}, ...}."""
+    e = fixture
+    T = int(e['T']) if T is None else T
+    steps = e['moment_steps']
+    xf = e[f'{mode}_exact_first_nan']
+    em, en, emom = e[f'{mode}_means'], e[f'{mode}_nell_cum'], e[f'{mode}_moments']
+    es = e['central_variances'] if mode == 'central' else e['scaled_scales']
+    sd = np.sqrt(es) if mode == 'central' else es
+    floor = moment_floor(emom)
+    R = len(xf)
+    out = np.zeros((R, 4))
+    finite_steps = np.zeros(R, dtype=np.int64)
+    for b in range(R):
+        hor = int(xf[b]) if xf[b] >= 0 else T
+        fin = np.isfinite(means[b]) & np.isfinite(second[b]) & (np.arange(T) < hor)
+        finite_steps[b] = int(fin.sum())
+        if not fin.any():
+            continue
+        with np.errstate(all='ignore'):
+            rm = np.abs(means[b] - em[b]) / np.maximum(sd[b], 1e-300)
+            rs = rel_err(second[b], es[b])
+            rmo = rel_err(moments[b][steps], emom[b], floor)
+        out[b, 0], out[b, 1] = rm[fin].max(), rs[fin].max()
+        fs = fin[steps]
+        if fs.any():
+            out[b, 2] = rmo[fs].max()
+        if hor == T and fin[T - 1] and np.isfinite(nell[b]):
+            out[b, 3] = abs(nell[b] - en[b, T - 1]) / abs(en[b, T - 1])
+    names = ('mean_in_sd', 'variance' if mode == 'central' else 'scale', 'moments_all_orders', 'nll')
+    return {'per_replicate': out, 'finite_steps': finite_steps, 'replicates': R,
+            'max': {n: float(out[:, i].max()) for i, n in enumerate(names)},
+            'replicates_over_1e-6': {n: int((out[:, i] > 1e-6).sum()) for i, n in enumerate(names)}}

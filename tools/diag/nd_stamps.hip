@@ -37,6 +37,7 @@ int run(int argc, char** argv) {
     const char* sub2[] = {"    cheb: Gershgorin", "    cheb: samples + coefficients", "    cheb: recurrence", "    cheb: K h"};
     for (int i = 0; i < 4; ++i) printf("%-36s %10.0f cycles per step\n", sub2[i], (double)st[16 + i] / st[9]);
     printf("    mean Chebyshev degree %.1f\n", (double)st[20] / st[9]);
+    printf("  front end (x2): load + elimination %.0f, block solves %.0f cycles per step\n", (double)st[21] / st[9], (double)st[22] / st[9]);
     unsigned long long hist[8][40]; hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_nd_hist), sizeof(hist));
     for (int t = 0; t < 8; ++t) {
         unsigned long long n = 0; for (int k = 0; k < 40; ++k) n += hist[t][k];
