@@ -744,6 +744,20 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
             return fail(MFS_EINVAL, "bad description of likelihood factor %d", f);
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (!multi_indices || !inds || !model->coef || !model->lik) return fail(MFS_EINVAL, "NULL buffer");
+    {   // The kernels compute the gather of quadratures.py:151-152 arithmetically from the graded-lex order of
+        // multi_indices.py:139-229 (d = 2: the index of (a0, a1) is (a0 + a1)(a0 + a1 + 1) / 2 + a0); a caller's table must be that one.
+        const int S = ke.S;
+        auto deg = [](int i) { int m = 0; while ((m + 1) * (m + 2) / 2 <= i) ++m; return m; };
+        for (int t = 0; t < 3; ++t)
+            for (int i = 0; i < S; ++i)
+                for (int j = 0; j < S; ++j) {
+                    const int mi = deg(i), mj = deg(j), ui = i - mi * (mi + 1) / 2, uj = j - mj * (mj + 1) / 2;
+                    const int M = mi + mj + (t > 0), want = M * (M + 1) / 2 + ui + uj + (t == 1);
+                    if (inds[(size_t)t * S * S + i * S + j] != want)
+                        return fail(MFS_EUNSUPPORTED, "inds[%d][%d][%d] = %d is not the graded-lexicographic Gram / Hankel table (expected %d)",
+                                    t, i, j, inds[(size_t)t * S * S + i * S + j], want);
+                }
+    }
     // the kernel derives a moment's multi-index from its position: insist on the graded-lex table
     for (int s = 0, zi = 0; s < 2 * N; ++s)
         for (int n0 = 0; n0 <= s; ++n0, ++zi)

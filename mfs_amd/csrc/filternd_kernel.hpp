@@ -169,6 +169,9 @@ struct NdTile {
     static constexpr int NCH = 32;
     static constexpr int oChX = (oPw + 2 * NPW + 1) & ~1;    // [NCH]
     static constexpr int oChC = oChX + NCH;                  // [sample j][coefficient i]: cos(pi i (j + 1/2) / NCH)
+    // (a 4 NCH-entry table of cos(pi m / (2 NCH)) indexed by i (2j + 1) mod 4 NCH would save 7 KB, but the per-lane addresses
+    //  doubled the time of the coefficient transform -- 3.6 k -> 7.8 k cycles per step -- and a third workgroup per CU, which
+    //  the 7 KB could buy, needs a 168-register build that spills 234 registers and is slower at every batch size)
     static constexpr int nChV = (2 * NP > NCH) ? 2 * NP : NCH;   // two vectors of NP, or the NCH samples
     static constexpr int oChW = oChC + NCH * NCH;            // [2][NCH + nChV + 8]
     static constexpr int nChW = NCH + nChV + 8;
@@ -1346,8 +1349,14 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
 }
 
 // TK = 0: operator-table transition (sde_cond_moments_tme); TK = 1: Normal closure (tme_normal / Euler--Maruyama)
+// workgroups per CU the register budget is sized for.  Two: a 168-register build (three) spills 234 registers and measured
+// slower at B = 512 (4.1 vs 3.0 ms per 100 steps) AND at B = 2048 (14.2 vs 11.7); MFS_ND_OCC overrides it for A/B runs.
+#ifndef MFS_ND_OCC
+#define MFS_ND_OCC 2
+#endif
+template <int N, int TK> constexpr int nd_occ() { return MFS_ND_OCC; }
 template <int N, int TK>
-__global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) {
+__global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
     constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = L::kMaxD * L::kMaxD;
@@ -1486,13 +1495,31 @@ __global__ __launch_bounds__(256, 2) void filternd_kernel(const FilterNdArgs a) 
                         nlow = max(nlow, max(a.ext[row] & 0xff, a.ext[row] >> 8));
                     }
                     if (tid < 2 * NP) Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
-                    __syncthreads();
-                    krylov_nd<N, TK>(Sm, nlow, 3, 0.0, 0.0);
-                    __syncthreads();
-                    ND_STAMP(10);
                     const int maxdeg = P - 1 + 2 * (a.D - 1);     // highest total degree a re-centred block reaches from a moment
-                    bilinear_moments_nd<N, TK>(Sm, nlow, 2 * (nlow - 1), scale0, scale1, 1.0);
-                    __syncthreads();
+                    if (2 * (nlow - 1) <= P - 1) {
+                        // ... which the rule reproduces: its moments of total degree <= 2N - 1 about its own centre ARE the
+                        // moments it was built from (quadratures.py:120-178; tests/test_multi_dim_quadrature.py:90-98 hold that
+                        // to 1e-12), so the corner is read off the moment vector -- no Krylov steps, no dot products
+                        for (int e = tid; e < nlow * nlow; e += 256) {
+                            const int pp = e / nlow, q = e - pp * nlow, dg = pp + q;
+                            double v = 0.0;
+                            if (dg <= 2 * (nlow - 1)) {
+                                v = mom[dg * (dg + 1) / 2 + pp];
+                                for (int k2 = 0; k2 < pp; ++k2) v *= scale0;
+                                for (int k2 = 0; k2 < q; ++k2) v *= scale1;
+                            }
+                            M[pp * MLD + q] = v;
+                        }
+                        __syncthreads();
+                        ND_STAMP(10);
+                    } else {     // (orders too low for that: a few Krylov steps from e_0)
+                        __syncthreads();
+                        krylov_nd<N, TK>(Sm, nlow, 3, 0.0, 0.0);
+                        __syncthreads();
+                        ND_STAMP(10);
+                        bilinear_moments_nd<N, TK>(Sm, nlow, 2 * (nlow - 1), scale0, scale1, 1.0);
+                        __syncthreads();
+                    }
                     ND_STAMP(11);
                     // ---- sums of the mean rows (and, scaled mode, the variance rows) of the table over the rule: each is a
                     //      polynomial in x = xi + mean, so sum W Q(x) = sum_{al,be} Q'[al][be] M[al][be] with Q' the block

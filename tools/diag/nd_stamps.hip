@@ -3,6 +3,7 @@
 #include "../../mfs_amd/csrc/filternd_kernel.hpp"
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 using namespace mfs;
 template <int TK>
 int run(int argc, char** argv) {
@@ -14,6 +15,12 @@ int run(int argc, char** argv) {
     std::vector<int> inds(3 * s * s);
     fread(coef.data(), 8, coef.size(), f); fread(lik.data(), 8, 4, f); fread(inds.data(), 4, inds.size(), f);
     fread(m0.data(), 8, z, f); fread(mean0.data(), 8, 2, f); fread(ys.data(), 8, ys.size(), f); fclose(f);
+    if (argc > 3) {   // timing run: tile the measurement rows up to the requested batch
+        const int B2 = atoi(argv[3]);
+        std::vector<double> y2((size_t)B2 * T);
+        for (int b = 0; b < B2; ++b) for (int t = 0; t < T; ++t) y2[(size_t)b * T + t] = ys[(size_t)(b % B) * T + t];
+        ys.swap(y2); B = B2;
+    }
     double *dc, *dl, *dm, *dmean, *dys, *dnell, *dmeans; int* di;
     hipMalloc(&dc, coef.size() * 8); hipMalloc(&dl, 32); hipMalloc(&dm, z * 8); hipMalloc(&dmean, 16);
     hipMalloc(&dys, ys.size() * 8); hipMalloc(&dnell, B * 8); hipMalloc(&di, inds.size() * 4); hipMalloc(&dmeans, (size_t)B * T * 16);
@@ -27,6 +34,15 @@ int run(int argc, char** argv) {
     constexpr int lds = NdTile<N, TK>::kDoubles * 8;
     hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(B), dim3(256), lds, 0, a);
     hipDeviceSynchronize();
+    if (argc > 3) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(B), dim3(256), lds, 0, a);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        printf("B = %d, T = %d: %.3f ms per pass (diagnostic build, stamps on), lds %d B\n", B, T, ms / 3, lds);
+        return 0;
+    }
     unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
     const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls / Chebyshev-grid rule", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
     double tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
