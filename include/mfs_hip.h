@@ -60,6 +60,8 @@ extern "C" {
                                         (ss_models.py:43-47; multi_dims/ss_models.py:63-67 on x_0) */
 #define MFS_LIK_POISSON_SOFTPLUS 1   /* rate = log(1 + exp(l0 x)), Poisson pmf(y; rate) (ss_models.py:80-84) */
 #define MFS_LIK_GAUSSIAN 2           /* y ~ N(l0 x + l1, l2) (l2 = variance) (convergence_mf.py:58-61) */
+#define MFS_LIK_BEARING_GAUSSIAN 3   /* N-D only, a factor of BOTH state components (fac_component = 2): y ~ N(atan2(x_1, x_0), l0),
+                                        l0 = variance (examples/2d_bearing_only.ipynb cell 7); Normal-closure transitions only */
 
 #define MFS_MAX_N 32       /* quadrature order N (2N moments) */
 #define MFS_MAX_TERMS 8    /* K <= 2 * tme_order */

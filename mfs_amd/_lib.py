@@ -12,7 +12,7 @@ MODE = {'raw': 0, 'central': 1, 'scaled': 2}
 MODE_ODD_TAIL = 0x100   # MFS_MODE_ODD_TAIL: 2N + 1 moments per row (include/mfs_hip.h)
 TRANS = {'operator': 0, 'gaussian': 1}
 UMAP = {'x': 0, 'tanh': 1}
-LIK = {'bernoulli_logistic': 0, 'poisson_softplus': 1, 'gaussian': 2}
+LIK = {'bernoulli_logistic': 0, 'poisson_softplus': 1, 'gaussian': 2, 'bearing_gaussian': 3}
 MAX_N = 32
 
 c_double_p = C.POINTER(C.c_double)

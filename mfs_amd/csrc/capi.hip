@@ -30,7 +30,7 @@ using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t
 struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes, carry_doubles; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
 hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s);
-extern Filter1dGradLaunch g_grad_table[11][5];  // filter1d_grad_inst.hip: [N <= 10][P <= 4]
+extern Filter1dGradLaunch g_grad_table[17][5];  // filter1d_grad_inst.hip: [N <= 16][P <= 4]
 }
 
 namespace {
@@ -474,7 +474,7 @@ int mfs_filter_1d_grad(const mfs_model_1d* model, const double* dcoef, const dou
     if (int rc = check_model(model, mode)) return rc;
     if (mode & MFS_MODE_ODD_TAIL) return fail(MFS_EUNSUPPORTED, "the gradient entry point takes 2N moments");
     if (n_par < 1 || n_par > 4) return fail(MFS_EUNSUPPORTED, "n_par = %d outside [1, 4]", n_par);
-    if (N < 2 || N > 10) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, 10] for the gradient kernel", N);
+    if (N < 2 || N > 16) return fail(MFS_EUNSUPPORTED, "N = %d outside [2, 16] for the gradient kernel", N);
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (!dcoef || !dlik || !m0 || !out_nell || !out_grad || (T > 0 && B > 0 && !ys)) return fail(MFS_EINVAL, "NULL buffer");
     if (mode != MFS_MODE_RAW && !mean0) return fail(MFS_EINVAL, "mean0 is required in central / scaled mode");
@@ -737,11 +737,17 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
     if (model->n_factors < 1 || model->n_factors > MFS_ND_MAX_FACTORS)
         return fail(MFS_EINVAL, "n_factors %d outside [1, %d]", model->n_factors, MFS_ND_MAX_FACTORS);
     if (model->ny < 1 || model->ny > 2) return fail(MFS_EINVAL, "ny %d outside [1, 2]", model->ny);
-    for (int f = 0; f < model->n_factors; ++f)
-        if (model->fac_kind[f] < 0 || model->fac_kind[f] > MFS_LIK_GAUSSIAN || model->fac_n_par[f] < 1 ||
-            model->fac_n_par[f] > MFS_MAX_LIK || model->fac_component[f] < 0 || model->fac_component[f] > 1 ||
-            model->fac_ycol[f] < 0 || model->fac_ycol[f] >= model->ny)
+    for (int f = 0; f < model->n_factors; ++f) {
+        const bool joint = model->fac_kind[f] == MFS_LIK_BEARING_GAUSSIAN;     // a factor of both components: component 2
+        if (model->fac_kind[f] < 0 || model->fac_kind[f] > MFS_LIK_BEARING_GAUSSIAN || model->fac_n_par[f] < 1 ||
+            model->fac_n_par[f] > MFS_MAX_LIK || model->fac_component[f] < 0 || model->fac_component[f] > 2 ||
+            (model->fac_component[f] == 2) != joint || model->fac_ycol[f] < 0 || model->fac_ycol[f] >= model->ny)
             return fail(MFS_EINVAL, "bad description of likelihood factor %d", f);
+        if (joint && (model->n_factors != 1 || model->trans_kind != MFS_ND_TRANS_GAUSSIAN))
+            return fail(MFS_EUNSUPPORTED, "a likelihood of both state components is integrated over the node set of a Normal-closure "
+                                          "prediction: one such factor, with sde_cond_moments_tme_normal / _euler_maruyama / "
+                                          "cond_moments_linear_gaussian");
+    }
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (!multi_indices || !inds || !model->coef || !model->lik) return fail(MFS_EINVAL, "NULL buffer");
     {   // The kernels compute the gather of quadratures.py:151-152 arithmetically from the graded-lex order of
@@ -791,7 +797,10 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
         a.fac_kind[f] = model->fac_kind[f]; a.fac_comp[f] = model->fac_component[f]; a.fac_ycol[f] = model->fac_ycol[f];
     }
     a.coef_batched = model->coef_batched; a.lik_batched = model->lik_batched;
-    if (const char* e = getenv("MFS_ND_UPDATE")) a.force_eigen = (strcmp(e, "eigen") == 0);   // A/B switch, like MFS_SOLVER
+    if (const char* e = getenv("MFS_ND_UPDATE")) {   // A/B switches, like MFS_SOLVER
+        a.force_eigen = (strcmp(e, "eigen") == 0);
+        a.joint_grid = (strcmp(e, "grid") == 0);
+    }
     // true extents of each coefficient block (trailing zero rows / columns cut); the union over replicates when batched
     const size_t ntab = model->coef_batched ? (size_t)B : 1;
     for (int k = 0; k < n_rows; ++k) {

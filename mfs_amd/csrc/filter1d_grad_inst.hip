@@ -1,11 +1,11 @@
-// filter1d_grad_inst.hip -- instantiates the forward-mode gradient kernels (N = 2..10 quadrature nodes, P = 1..4
+// filter1d_grad_inst.hip -- instantiates the forward-mode gradient kernels (N = 2..16 quadrature nodes, P = 1..4
 // parameters; 16 lanes per filter) and registers their launchers.
 #include "filter1d_grad.hpp"
 #include "launch_util.hpp"
 
 namespace mfs {
 
-constexpr int kGradMaxN = 10, kGradMaxP = 4;
+constexpr int kGradMaxN = 16, kGradMaxP = 4;
 Filter1dGradLaunch g_grad_table[kGradMaxN + 1][kGradMaxP + 1];
 
 template <int N, int P>

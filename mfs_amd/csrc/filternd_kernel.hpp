@@ -56,6 +56,7 @@ struct FilterNdArgs {
     int fac_kind[2], fac_comp[2], fac_ycol[2];
     int coef_batched, lik_batched;
     int force_eigen;          // 1: every update diagonalises K_k (the checked fallback of the Chebyshev evaluation, as the only route)
+    int joint_grid;           // 1: a likelihood of both components is integrated over the Chebyshev grid instead of the eigen-nodes (A/B)
     int ext[32];              // per-block true extents (ea | eb << 8) of the coefficient blocks; 0 = empty block
     const double* coef;       // [rows][D][D] (or [B][...]), rows = terms + 2 with terms = 14 or 27 (see nd_terms): Q_kappa in the
                               // fixed kappa order below (zeros where the model has no term), then the conditional variances
@@ -120,13 +121,16 @@ struct NdTile {
     static constexpr int HP = NP / 2;
     static constexpr int LD = NP + 1;
     static constexpr int R = S * S;                  // tensor-product nodes
+    static constexpr int kNcpMax = (N <= 6) ? 34 : 28;     // largest Chebyshev grid per variable; 34 = 3 (2 N - 1) + 1 at N = 6: TME-normal-3 of a quadratic drift
     static constexpr int oMom = 0;
     static constexpr int oK = (Z + 1) & ~1;          // [2][NP][LD]
     static constexpr int oV = oK + 2 * NP * LD;      // [2][NP][LD]
-    static constexpr int oCs = oV + 2 * NP * LD;     // [2][HP][3]
+    // (Normal closures: the Chebyshev-grid rule parks its cardinal vectors [2][NCP][NP] in the tiles of K_0, K_1, V_0, V_1; at small
+    //  N those are smaller than that, hence the pad)
+    static constexpr int kUoPad = (TK == 1 && 2 * kNcpMax * NP > 4 * NP * LD) ? 2 * kNcpMax * NP - 4 * NP * LD : 0;
+    static constexpr int oCs = oV + 2 * NP * LD + kUoPad;     // [2][HP][3]
     // Normal closures integrate over s^2 eigen-nodes (weights W, coordinates lam) or -- when the integrand's degree allows --
     // over an NCP x NCP Chebyshev grid with the weights Omega of the same bilinear form (kNcpMax bounds NCP)
-    static constexpr int kNcpMax = 28;
     static constexpr int LS = (NP > kNcpMax) ? NP : kNcpMax;           // stride of the two coordinate lists
     static constexpr int nWt = (R > kNcpMax * kNcpMax) ? R : kNcpMax * kNcpMax;
     static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] / [NCP][NCP] node weights (Normal closures)
@@ -159,7 +163,8 @@ struct NdTile {
     static_assert((S + N + 1) * (S + 1) + S <= 2 * NPW * NP && NP * LD <= 2 * NPW * NP, "front-end tiles alias the Krylov tiles");
     static constexpr int oM = oPK + 2 * NPW * NP;            // [NPW][MLD]
     static constexpr int oM2 = oM + NPW * MLD;               // [NPW][MLD]
-    static constexpr int oQs = oM2 + NPW * MLD;              // [kRows][kMaxD * kMaxD] (operator path)
+    static constexpr int kUPad = (TK == 1 && 2 * kNcpMax * NP > 2 * NPW * NP + 2 * NPW * MLD) ? 2 * kNcpMax * NP - (2 * NPW * NP + 2 * NPW * MLD) : 0;
+    static constexpr int oQs = oM2 + NPW * MLD + kUPad;      // [kRows][kMaxD * kMaxD] (operator path)
     static constexpr int oBin = oQs + (kOperator ? kRows * kMaxD * kMaxD : 0);  // [NPW][NPW] binomial coefficients
     static constexpr int oBx = oBin + NPW * NPW;             // [kMaxD][kMaxD] spare, then 8 scalars
     static constexpr int oLik = oBx + kMaxD * kMaxD + 8; // [2][4] likelihood factor parameters
@@ -194,7 +199,7 @@ struct NdTile {
     static constexpr int oChG = oChD + ((TK == 1) ? kNcpMax * kNcpMax : 0);
     static constexpr int kDoubles = oChG + ((TK == 1) ? kNcpMax : 0);
     static constexpr int oU = oPK;
-    static_assert(2 * kNcpMax * NP <= 2 * NPW * NP + 2 * NPW * MLD, "Chebyshev-grid vectors must fit in the Krylov and moment-array tiles");
+    static_assert(TK != 1 || 2 * kNcpMax * NP <= 2 * NPW * NP + 2 * NPW * MLD + kUPad, "Chebyshev-grid vectors must fit in the Krylov and moment-array tiles");
     static constexpr int kCarry = Z + 8 + 2 * NP * LD;   // per-replicate state between the chunk launches of one run
     static constexpr int oJs = (TK == 1) ? oW : oM;
     static_assert(S * S <= 2 * NPW * MLD, "Jacobi scratch must fit in the moment-array tiles");
@@ -284,6 +289,17 @@ __device__ __forceinline__ double likelihood_nd(const int kind, const double* __
         return (y > 0.5) ? p : 1.0 - p;
     }
     return likelihood(kind, lp, y, x);
+}
+
+// a factor of BOTH state components (fac_component = 2).  MFS_LIK_BEARING_GAUSSIAN: y ~ N(atan2(x_1, x_0), lp[0]) -- the
+// bearing-only measurement of /root/reference/examples/2d_bearing_only.ipynb cell 7, norm.pdf(y, arctan2(x[1], x[0]), sd)
+__device__ __forceinline__ double likelihood_joint_nd(const int kind, const double* __restrict__ lp, const double y,
+                                                      const double x0, const double x1) {
+    if (kind == MFS_LIK_BEARING_GAUSSIAN) {
+        const double r = y - atan2(x1, x0);
+        return fast_exp(-0.5 * r * r * rcp_nr(lp[0])) * rsq_nr(6.283185307179586476925 * lp[0]);
+    }
+    return __builtin_nan("");
 }
 
 // acc[j] -= u * (v of lane j - OFF of this lane's DPP row) for j = J0 .. J1 - 1 as blocks of 8 / 4 / 2 / 1 fused DPP
@@ -1312,19 +1328,24 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
     for (int e = tid; e < 2 * ncp * S; e += 256) {
         const int w = e / (ncp * S), f = e - w * ncp * S, pp = f / S, r = f - pp * S;
         const double* tw = U + w * ncp * NP + r;
-        // fixed trip count, every LDS read issued before the arithmetic (terms a >= ncp masked by a select)
-        double dv[NCM], tv[NCM];
-        static_for<0, NCM>([&](auto Ac) {
-            const int ai = (Ac < ncp) ? (int)Ac : 0;
-            dv[Ac] = Dt[ai * ncp + pp];
-            tv[Ac] = tw[ai * NP];
-        });
+        // fixed trip count in chunks of 17 terms, the LDS reads of a chunk issued before its arithmetic (terms a >= ncp masked
+        // by a select)
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        static_for<0, NCM>([&](auto Ac) {
-            const double t = (Ac < ncp) ? tv[Ac] : 0.0;
-            if constexpr (Ac % 3 == 0) a0 = fma(dv[Ac], t, a0);
-            else if constexpr (Ac % 3 == 1) a1 = fma(dv[Ac], t, a1);
-            else a2 = fma(dv[Ac], t, a2);
+        constexpr int CHK = 17;
+        static_for<0, (NCM + CHK - 1) / CHK>([&](auto Cc) {
+            constexpr int c0 = Cc * CHK, c1 = (c0 + CHK < NCM) ? c0 + CHK : NCM;
+            double dv[CHK], tv[CHK];
+            static_for<c0, c1>([&](auto Ac) {
+                const int ai = (Ac < ncp) ? (int)Ac : 0;
+                dv[Ac - c0] = Dt[ai * ncp + pp];
+                tv[Ac - c0] = tw[ai * NP];
+            });
+            static_for<c0, c1>([&](auto Ac) {
+                const double t = (Ac < ncp) ? tv[Ac - c0] : 0.0;
+                if constexpr (Ac % 3 == 0) a0 = fma(dv[Ac - c0], t, a0);
+                else if constexpr (Ac % 3 == 1) a1 = fma(dv[Ac - c0], t, a1);
+                else a2 = fma(dv[Ac - c0], t, a2);
+            });
         });
         Uo[(w * ncp + pp) * NP + r] = (a0 + a1) + a2;
     }
@@ -1438,8 +1459,11 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
     double* red = Sm + L::oRed;
     if (tid == 0) { red[16 * ZB] = 0.0; Sm[L::oMisc + 5] = resume ? cw[Z + 5] : __hiloint2double(0, -1); }   // flag slot 1: step of the first non-finite result (an int in the low word)
     // which matrices an update diagonalises: the components a likelihood factor reads
+    // (component 2 = a factor of BOTH components, e.g. a bearing measurement: no bilinear form of matrix functions exists for
+    //  it; Normal-closure kernels integrate it over their node set -- Chebyshev grid or eigen-nodes -- like the prediction)
+    const bool joint = (TK == 1) && a.n_factors == 1 && a.fac_comp[0] == 2;
     int lik_mask = 0;
-    for (int f = 0; f < a.n_factors; ++f) lik_mask |= 1 << a.fac_comp[f];
+    for (int f = 0; f < a.n_factors; ++f) lik_mask |= (a.fac_comp[f] < 2) ? (1 << a.fac_comp[f]) : 0;
     const int ubeg = (lik_mask & 1) ? 0 : 1, uend = (lik_mask & 2) ? 2 : 1;
     // Normal closure: the size of the Chebyshev grid that integrates every moment's integrand exactly (cheb_grid_rule_nd), from
     // the per-variable degrees of mu (rows 0, 1) and Sigma (rows 2 .. 4); 0 = too large for the tables, eigen-nodes instead
@@ -1452,7 +1476,8 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
         }
         const int g = max(1, max(dmu, (dsg + 1) / 2));
         ncp = g * (P - 1) + 1;
-        if (ncp > L::kNcpMax || 2 * ncp > 4 * LD || a.force_eigen) ncp = 0;   // (table size; the cardinal vectors' room)
+        if (joint && a.joint_grid) ncp = L::kNcpMax;     // (A/B: a joint likelihood on the same grid -- take all the tables hold)
+        if (ncp > L::kNcpMax || a.force_eigen) ncp = 0;   // (table size)
         if (ncp > 0) {
             for (int e = tid; e < ncp * ncp; e += 256) {
                 const int aa = e / ncp, pp = e - aa * ncp;
@@ -1782,9 +1807,84 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 ND_STAMP_BEGIN;
                 if (tid == 0) Sm[L::oMisc + 6] = 0.0;
                 __syncthreads();
+                double c0 = 0.0, c1 = 0.0;
+                bool done_joint = false;
+                if constexpr (TK == 1) {
+                  if (joint) {
+                    // ---- a likelihood of both components (filtering.py:263-275 evaluates measurement_cond_pdf at the tensor
+                    //      nodes for ANY callable): sum_ij W_ij l(y, x_ij) xi_0^a xi_1^b over the node set of the Normal-closure
+                    //      prediction.  Default: the reference's own s^2 eigen-nodes (both K_k diagonalised by cyclic Jacobi, weights
+                    //      from the eigenvectors, quadratures.py:163-170) -- no assumption on l at all; on the bearing-only example
+                    //      (N = 4) NLL 4e-13, moments 4e-10 from the oracle.  MFS_ND_UPDATE=grid: the NCP x NCP Chebyshev grid with
+                    //      the weights Omega of the rule's bilinear form, exact for polynomial integrands only -- l is interpolated
+                    //      on a Gershgorin box, which on the same example costs the odd high moments five digits (7e-5)
+                    done_joint = true;
+                    int Rn = R, Sn = S;
+                    if (a.joint_grid && ncp > 0) {
+                        cheb_grid_rule_nd<N, TK>(Sm, ncp);
+                        Rn = ncp * ncp; Sn = ncp;
+                        warm_mask = 0;
+                    } else {
+                        jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
+                        weights_nd<N, TK>(Sm);
+                        warm_mask = poisoned ? 0 : 3;
+                    }
+                    constexpr int LS = L::LS;
+                    const double* lam = Sm + L::oLam;
+                    const double* W = Sm + L::oW;
+                    const double yv = yrow[(size_t)t * a.ny + a.fac_ycol[0]];
+                    const int lane16 = tid & 15;
+                    const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
+                    double* myred = red + (tid >> 4) * RW + cls;
+                    for (int base = 0; base < Rn; base += 256) {
+                        const int eA = base + tid;
+                        const bool okA = eA < Rn;
+                        const int iA0 = okA ? eA / Sn : 0, iA1 = okA ? eA - iA0 * Sn : 0;
+                        const double xi0 = lam[iA0] * scale0, xi1 = lam[LS + iA1] * scale1;      // node - mean
+                        const double wl = okA ? W[eA] * likelihood_joint_nd(a.fac_kind[0], Sm + L::oLik, yv, xi0 + mean0, xi1 + mean1) : 0.0;
+                        double MA[2][P], bt[16];
+                        static_for<0, P>([&](auto N0c) {
+                            constexpr int n0 = N0c, r = n0 % 2, r1 = (n0 + 1) % 2;
+                            static_for<0, P - n0>([&](auto N1c) {
+                                constexpr int n1 = N1c;
+                                double vA;
+                                if constexpr (n0 == 0) { if constexpr (n1 == 0) vA = wl; else vA = xi1 * MA[0][n1 - 1]; }
+                                else vA = xi0 * MA[r1][n1];
+                                MA[r][n1] = vA;
+                                constexpr int e = n0 * P - n0 * (n0 - 1) / 2 + n1;
+                                bt[e % 16] = vA;
+                                if constexpr (e % 16 == 15 || e == Z - 1) {
+                                    if constexpr (e % 16 != 15) static_for<e % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
+                                    const double v = row_reduce16(bt, lane16);
+                                    double* slot = myred + 16 * (e / 16);
+                                    *slot = (base == 0) ? v : *slot + v;
+                                }
+                            });
+                        });
+                    }
+                    __syncthreads();
+                    for (int zi = tid; zi < Z; zi += 256) {          // the sums about the OLD mean into the moment array
+                        int sd = 0;
+                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
+                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                        const int e = n0 * P - n0 * (n0 - 1) / 2 + n1;
+                        double v = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) v += red[q * RW + e];
+                        M[n0 * MLD + n1] = v;
+                    }
+                    __syncthreads();
+                    const double py = M[0];
+                    const double ipy = 1.0 / py;
+                    if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
+                    nell -= fast_log(py);
+                    __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
+                    shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
+                  }
+                }
+                if (!done_joint) {
                 cheb_h_nd<N, TK>(Sm, a, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
                 __syncthreads();
-                double c0 = 0.0, c1 = 0.0;
                 if (MFS_ND_FORCE_JACOBI || a.force_eigen || Sm[L::oMisc + 6] != 0.0) {
                     jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
                     warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
@@ -1863,6 +1963,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, ipy);
                     __syncthreads();
                 }
+                }   // (separable likelihood)
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
                 for (int zi = tid; zi < Z; zi += 256) {

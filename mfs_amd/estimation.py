@@ -30,21 +30,8 @@ _STENCIL = np.array([-2., -1., 1., 2.])
 _WEIGHTS = np.array([1., -8., 8., -1.]) / 12.
 
 
-def _tables_and_tangents(model: Callable, params: np.ndarray, mode: str, rel_step: float):
-    """Trace `model` at params and on the stencil.  params (P,) or (R, P).  Returns the centre tables / likelihood and
-    d coef (R?, P, rows, J + 1), d lik (R?, P, n_lik)."""
+def _trace(model, flat, mode):
     from mfs_amd.one_dim import filtering
-    params = np.asarray(params, dtype=np.float64)
-    batched = params.ndim == 2
-    pts0 = params if batched else params[None, :]
-    R, P = pts0.shape
-    h = rel_step * np.maximum(np.abs(pts0), 1.0)                     # (R, P)
-    # evaluation points: centre, then for every parameter the four stencil points -> (1 + 4P, R, P)
-    pts = np.broadcast_to(pts0, (1 + 4 * P, R, P)).copy()
-    for j in range(P):
-        for s, off in enumerate(_STENCIL):
-            pts[1 + 4 * j + s, :, j] += off * h[:, j]
-    flat = pts.reshape(-1, P)                                       # ((1 + 4P) R, P): one traced model, batched tables
     closures = model(flat)
     if len(closures) == 3:
         trans, mean_fn, pdf = closures
@@ -56,22 +43,81 @@ def _tables_and_tangents(model: Callable, params: np.ndarray, mode: str, rel_ste
     coef, J = tables.table(nb)
     if coef.ndim == 2:
         coef = np.broadcast_to(coef, (nb,) + coef.shape)
-    lp = np.asarray(lik.params, dtype=np.float64)
+    lp = np.asarray(lik.params)
     if lp.ndim == 1:
         lp = np.broadcast_to(lp, (nb,) + lp.shape)
-    coef = coef.reshape((1 + 4 * P, R) + coef.shape[1:])
-    lp = lp.reshape((1 + 4 * P, R) + lp.shape[1:])
-    dcoef = np.empty((R, P) + coef.shape[2:])
-    dlik = np.empty((R, P) + lp.shape[2:])
-    for j in range(P):
-        sl = slice(1 + 4 * j, 5 + 4 * j)
-        dcoef[:, j] = np.tensordot(_WEIGHTS, coef[sl], axes=(0, 0)) / h[:, j][:, None, None]
-        dlik[:, j] = np.tensordot(_WEIGHTS, lp[sl], axes=(0, 0)) / h[:, j][:, None]
-    return tables, lik, coef[0], lp[0], dcoef, dlik, batched, J
+    return tables, lik, coef, lp, J
+
+
+def _tables_and_tangents(model: Callable, params: np.ndarray, mode: str, rel_step: float, tangents: str = 'complex-step'):
+    """Trace `model` at params and obtain d tables / d theta.  params (P,) or (R, P).  Returns the centre tables / likelihood
+    and d coef (R?, P, rows, J + 1), d lik (R?, P, n_lik).
+
+    tangents = 'complex-step' (default): the model is traced ONCE more with complex parameters theta + i h e_p (h = 1e-30 |theta|);
+        every table entry is an analytic function of theta built from the model's own arithmetic, so Im(entry) / h is its exact
+        derivative -- the derivative of the traced polynomials themselves, with no truncation or cancellation error whatever the
+        dependence on theta (exp, softplus, products, ...).  The model must not apply non-analytic operations to its
+        parameters (abs, comparisons, casts to float): if the complex trace raises, or disagrees with the stencil below by
+        more than 1e-5, the stencil is used and a warning says so.
+    tangents = 'stencil': five-point central differences on the table builder (`rel_step`), exact for tables polynomial in
+        theta up to degree four."""
+    from mfs_amd import sym
+    params = np.asarray(params, dtype=np.float64)
+    batched = params.ndim == 2
+    pts0 = params if batched else params[None, :]
+    R, P = pts0.shape
+
+    def stencil():
+        h = rel_step * np.maximum(np.abs(pts0), 1.0)                     # (R, P)
+        pts = np.broadcast_to(pts0, (1 + 4 * P, R, P)).copy()
+        for j in range(P):
+            for s_, off in enumerate(_STENCIL):
+                pts[1 + 4 * j + s_, :, j] += off * h[:, j]
+        tables, lik, coef, lp, J = _trace(model, pts.reshape(-1, P), mode)
+        coef = coef.reshape((1 + 4 * P, R) + coef.shape[1:])
+        lp = lp.reshape((1 + 4 * P, R) + lp.shape[1:])
+        dcoef = np.empty((R, P) + coef.shape[2:])
+        dlik = np.empty((R, P) + lp.shape[2:])
+        for j in range(P):
+            sl = slice(1 + 4 * j, 5 + 4 * j)
+            dcoef[:, j] = np.tensordot(_WEIGHTS, coef[sl], axes=(0, 0)) / h[:, j][:, None, None]
+            dlik[:, j] = np.tensordot(_WEIGHTS, lp[sl], axes=(0, 0)) / h[:, j][:, None]
+        return tables, lik, coef[0], lp[0], dcoef, dlik, J
+
+    if tangents == 'stencil':
+        tables, lik, coef0, lp0, dcoef, dlik, J = stencil()
+        return tables, lik, coef0, lp0, dcoef, dlik, batched, J
+    if tangents != 'complex-step':
+        raise ValueError("tangents must be 'complex-step' or 'stencil'")
+    try:
+        h = 1e-30 * np.maximum(np.abs(pts0), 1.0)
+        pts = np.broadcast_to(pts0.astype(np.complex128), (1 + P, R, P)).copy()
+        for j in range(P):
+            pts[1 + j, :, j] += 1j * h[:, j]
+        with sym.coefficient_dtype(np.complex128):
+            tables_c, lik_c, coef, lp, J = _trace(model, pts.reshape(-1, P), mode)
+        coef = coef.reshape((1 + P, R) + coef.shape[1:])
+        lp = lp.reshape((1 + P, R) + lp.shape[1:])
+        if np.abs(coef[0].imag).max(initial=0.) != 0. or np.abs(lp[0].imag).max(initial=0.) != 0.:
+            raise TypeError('the unperturbed trace is not real')
+        dcoef = np.stack([coef[1 + j].imag / h[:, j][:, None, None] for j in range(P)], axis=1)
+        dlik = np.stack([lp[1 + j].imag / h[:, j][:, None] for j in range(P)], axis=1)
+        # the value tables and the model description come from a plain float64 trace (what the filters themselves use)
+        tables, lik, coef0, lp0, J0 = _trace(model, pts0, mode)
+        if J0 != J or coef0.shape != coef[0].shape or not np.allclose(coef0, coef[0].real, rtol=1e-13, atol=1e-300):
+            raise TypeError('complex and real traces disagree')
+        return tables, lik, coef0, lp0, dcoef, dlik, batched, J
+    except (TypeError, ValueError, ArithmeticError) as e:
+        import warnings
+        warnings.warn(f'complex-step trace of the model failed ({e!r}); using the five-point stencil for the parameter '
+                      'tangents of the tables (exact only for tables polynomial in the parameters up to degree four)')
+        tables, lik, coef0, lp0, dcoef, dlik, J = stencil()
+        return tables, lik, coef0, lp0, dcoef, dlik, batched, J
 
 
 def nell_and_grad_forward(model: Callable, params, ms0, mean0, ys, scale0=None, mode: str = 'central',
-                          rel_step: float = 1e-3, device: int = 0, return_first_nan: bool = False):
+                          rel_step: float = 1e-3, device: int = 0, return_first_nan: bool = False,
+                          tangents: str = 'complex-step'):
     """NLL and d NLL / d params of the moment filter, forward mode in the kernel.
 
     model(params) -> (state_cond_moments, state_cond_mean[_var], measurement_cond_pdf) for `mode` in
@@ -80,11 +126,11 @@ def nell_and_grad_forward(model: Callable, params, ms0, mean0, ys, scale0=None, 
                      dardel/parameter_estimation/mf.py:41-53 does (`drift(x, params[:, 0])`, ...)
     params           (P,): one parameter point for every trajectory in `ys`;  (R, P): one point per row of ys (R, T)
     ys               (T,) or (B, T)
-    Returns (nell (B,) or scalar, grad (B, P) or (P,)).  N <= 10, P <= 4.
+    Returns (nell (B,) or scalar, grad (B, P) or (P,)).  N <= 16, P <= 4.
     """
     from mfs_amd import _lib
     from mfs_amd.one_dim import filtering
-    tables, lik, coef, lp, dcoef, dlik, batched, J = _tables_and_tangents(model, params, mode, rel_step)
+    tables, lik, coef, lp, dcoef, dlik, batched, J = _tables_and_tangents(model, params, mode, rel_step, tangents)
     P = dcoef.shape[1]
     ys = np.asarray(ys, dtype=np.float64)
     squeeze = ys.ndim == 1 and not batched

@@ -11,7 +11,7 @@ from mfs_amd.multi_dims.multi_indices import find_indices
 from mfs_amd.tme_poly_nd import (TransitionTablesND, GaussianTablesND, BatchedTablesND, tme_tables_nd,
                                   normal_tables_nd)
 
-__all__ = ['raw_moments_mvn_kan', 'central_moments_mvn_kan', 'sde_cond_moments_tme', 'sde_cond_moments_tme_normal',
+__all__ = ['cond_moments_linear_gaussian', 'raw_moments_mvn_kan', 'central_moments_mvn_kan', 'sde_cond_moments_tme', 'sde_cond_moments_tme_normal',
            'sde_cond_moments_euler_maruyama', 'batch_closures', 'extract_moments',
            'extract_mean', 'extract_cov', 'marginalise_moments']
 
@@ -128,6 +128,28 @@ def sde_cond_moments_euler_maruyama(drift: Callable, dispersion: Callable, dt: f
     """Euler--Maruyama Normal closure (mfs/multi_dims/moments.py:257-337); 'index' signature."""
     mi = np.asarray(multi_indices)
     return _indexed_five(normal_tables_nd(drift, dispersion, mi.shape[-1], float(dt), 'euler'), mi)
+
+
+def cond_moments_linear_gaussian(F, Q, multi_indices):
+    """Normal closure of an exactly discretised linear SDE, X' | x ~ N(F x, Q) -- what
+    /root/reference/examples/2d_bearing_only.ipynb cell 7 writes by hand with `discretise_lti_sde` and `raw_moments_mvn_kan`:
+    `cms[index]` of E[(X' - mean)^n | x] for the multi-indices of the table; 'index' signature, same five closures as
+    `sde_cond_moments_tme_normal`."""
+    from mfs_amd.tme_poly_nd import GaussianTablesND, PolyND
+    mi = np.asarray(multi_indices)
+    F, Q = np.asarray(F, dtype=np.float64), np.asarray(Q, dtype=np.float64)
+    d = mi.shape[-1]
+    if F.shape != (d, d) or Q.shape != (d, d):
+        raise ValueError(f'F and Q must be ({d}, {d})')
+    xs = [PolyND.variable(d, k) for k in range(d)]
+    mean = []
+    for i in range(d):
+        acc = PolyND(np.float64(0.), d)
+        for k in range(d):
+            acc = acc + float(F[i, k]) * xs[k]
+        mean.append(acc.trimmed())
+    cov = [[PolyND(np.float64(0.5 * (Q[i, j] + Q[j, i])), d) for j in range(d)] for i in range(d)]
+    return _indexed_five(GaussianTablesND(d, mean, cov, 'linear_gaussian'), mi)
 
 
 def batch_closures(per_replicate):

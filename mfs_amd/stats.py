@@ -64,12 +64,15 @@ def norm_pdf(y, loc, scale):
     vec = _vectorised(norm_pdf, y, loc, scale)
     if vec is not None:
         return vec
+    if isinstance(loc, sym._Bearing):     # y ~ N(arctan2(x[1], x[0]), scale^2): a factor of both state components (component 2)
+        var = np.asarray(scale, dtype=sym._DTYPE[0]) ** 2
+        return sym.LikelihoodSpec('bearing_gaussian', var[..., None], component=2, ycol=_ycol(y))
     if isinstance(loc, sym.Poly):
         q = loc.trimmed()
         if q.umap not in (None, 'x') or q.degree > 1:
             raise sym.NotDeviceDescribable('Gaussian likelihood: loc must be l0 * x + l1')
         c = sym._pad(q.coef, 1)
-        var = np.asarray(scale, dtype=np.float64) ** 2
+        var = np.asarray(scale, dtype=sym._DTYPE[0]) ** 2
         lead = np.broadcast_shapes(c.shape[:-1], var.shape)      # per-replicate loc coefficients and / or scale
         c, var = np.broadcast_to(c, lead + (2,)), np.broadcast_to(var, lead)
         return sym.LikelihoodSpec('gaussian', np.stack([c[..., 1], c[..., 0], var], axis=-1), component=q.comp or 0,

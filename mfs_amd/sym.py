@@ -54,16 +54,43 @@ MEAN = _Placeholder('mean')    # the centre of central / scaled moments
 SCALE = _Placeholder('scale')
 
 
+# The dtype of every coefficient array the tracer builds.  float64, except while `mfs_amd.estimation` traces a model at
+# theta + i h e_p: the tables are analytic in the parameters, so Im(table) / h is their EXACT parameter derivative (the
+# complex-step derivative: no subtraction, hence no step-size compromise) -- what differentiating the traced polynomials
+# symbolically would give, for any dependence on theta the model's own arithmetic can express (exp(theta), softplus, ...).
+_DTYPE = [np.float64]
+
+
+class coefficient_dtype:
+    """Context manager: trace with coefficient arrays of `dtype` (np.complex128 for complex-step tangents)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = _DTYPE[0]
+        _DTYPE[0] = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        _DTYPE[0] = self.prev
+        return False
+
+
+def _zeros(shape):
+    return np.zeros(shape, dtype=_DTYPE[0])
+
+
 def _as_coef(c):
     """scalar -> shape (1,); array (B,) -> shape (B, 1) (a batched constant)."""
-    c = np.asarray(c, dtype=np.float64)
+    c = np.asarray(c, dtype=_DTYPE[0])
     return c.reshape(c.shape + (1,))
 
 
 def _pad(a, deg):
     if a.shape[-1] - 1 >= deg:
         return a
-    pad = np.zeros(a.shape[:-1] + (deg + 1 - a.shape[-1],))
+    pad = np.zeros(a.shape[:-1] + (deg + 1 - a.shape[-1],), dtype=a.dtype)
     return np.concatenate([a, pad], axis=-1)
 
 
@@ -73,7 +100,7 @@ class Poly:
     __array_ufunc__ = None  # ndarray (op) Poly defers to Poly.__r(op)__; np.sin(Poly) etc. raise TypeError
 
     def __init__(self, coef, umap=None, comp=None):
-        self.coef = np.asarray(coef, dtype=np.float64)
+        self.coef = np.asarray(coef, dtype=_DTYPE[0])
         if self.coef.ndim == 0:
             self.coef = self.coef.reshape(1)
         self.umap = umap
@@ -141,7 +168,7 @@ class Poly:
         umap = Poly._merge_umap(self, o)
         a, b = self.coef, o.coef
         shape = np.broadcast_shapes(a.shape[:-1], b.shape[:-1])
-        out = np.zeros(shape + (a.shape[-1] + b.shape[-1] - 1,))
+        out = _zeros(shape + (a.shape[-1] + b.shape[-1] - 1,))
         for i in range(a.shape[-1]):
             out[..., i:i + b.shape[-1]] += a[..., i:i + 1] * b
         return Poly(out, umap, Poly._merge_comp(self, o))
@@ -169,7 +196,7 @@ class Poly:
     def du(self):
         """d/du."""
         if self.degree == 0:
-            return Poly(np.zeros(self.coef.shape[:-1] + (1,)))
+            return Poly(_zeros(self.coef.shape[:-1] + (1,)))
         j = np.arange(1, self.degree + 1, dtype=np.float64)
         return Poly(self.coef[..., 1:] * j, self.umap)
 
@@ -242,6 +269,22 @@ class _Softplus(_Expr):  # log(1 + exp(q))
         self.q = q
 
 
+class _Bearing(_Expr):  # arctan2(x[1], x[0]) of the two tagged state components
+    pass
+
+
+def arctan2(x1, x0):
+    """numpy.arctan2 on numbers; on the traced state components x[1], x[0] (in that order, as
+    /root/reference/examples/2d_bearing_only.ipynb cell 7 writes it) the bearing of the state."""
+    if isinstance(x1, Poly) or isinstance(x0, Poly):
+        ok = all(isinstance(v, Poly) and v.umap in (None, 'x') and v.degree == 1 and np.all(_pad(v.coef, 1) == [0., 1.])
+                 for v in (x1, x0))
+        if not ok or x1.comp != 1 or x0.comp != 0:
+            raise NotDeviceDescribable('arctan2: the device takes arctan2(x[1], x[0]) of the plain state components')
+        return _Bearing()
+    return np.arctan2(x1, x0)
+
+
 def is_symbolic(v):
     return isinstance(v, (Poly, _Expr, _Placeholder))
 
@@ -289,14 +332,14 @@ def as_poly(v, what='expression'):
 
 class LikelihoodSpec:
     """Device description of p(y | x): kind in {'bernoulli_logistic', 'poisson_softplus', 'gaussian'}, params (..., P)."""
-    KINDS = {'bernoulli_logistic': 0, 'poisson_softplus': 1, 'gaussian': 2}
+    KINDS = {'bernoulli_logistic': 0, 'poisson_softplus': 1, 'gaussian': 2, 'bearing_gaussian': 3}
 
 
 
     def __init__(self, kind, params, component=0, ycol=0):
         assert kind in self.KINDS
         self.kind = kind
-        self.params = np.asarray(params, dtype=np.float64)
+        self.params = np.asarray(params, dtype=_DTYPE[0])
         self.component = component  # which state component the factor reads (N-D models)
         self.ycol = ycol            # which measurement column it reads (N-D models with vector measurements)
 

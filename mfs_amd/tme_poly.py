@@ -27,7 +27,7 @@ from typing import Dict, List
 
 import numpy as np
 
-from mfs_amd.sym import Poly, NotDeviceDescribable
+from mfs_amd.sym import Poly, NotDeviceDescribable, _zeros as sym_zeros
 
 MAX_TERMS = 8    # MFS_MAX_TERMS
 MAX_DEGREE = 15  # MFS_MAX_DEGREE
@@ -102,7 +102,7 @@ class TransitionTables:
         if J > MAX_DEGREE:
             raise NotDeviceDescribable(f'coefficient polynomial degree {J} exceeds MFS_MAX_DEGREE = {MAX_DEGREE}')
         bs = self.batch_shape()
-        out = np.zeros(bs + (len(rows), J + 1))
+        out = sym_zeros(bs + (len(rows), J + 1))
         for i, r in enumerate(rows):
             out[..., i, :r.degree + 1] = np.broadcast_to(r.coef, bs + (r.degree + 1,))
         if bs not in ((), (B,)) and B is not None:

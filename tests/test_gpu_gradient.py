@@ -125,3 +125,71 @@ def test_parameter_estimation_lbfgs_with_the_in_kernel_gradient():
     assert res_fw.launches <= res_fd.launches + 3
     g_end = estimation.nell_and_grad_forward(model, res_fw.x, ic.cms, ic.mean, ys[0])[1]
     assert np.max(np.abs(g_end)) < 1e-2 * max(1., abs(res_fw.fun))
+
+
+def test_gradient_at_the_headline_order_N15_and_exact_parameter_tangents():
+    """Benes--Bernoulli at N = 15 (the headline order), T = 100, theta = (drift gain, dispersion, logistic slope): the in-kernel
+    forward-mode gradient against (i) central differences of the device's own plain filter in one launch and (ii) Richardson-
+    extrapolated central differences of the NumPy oracle's NLL.  At N = 15 the oracle's NLL carries ~1e-10 of rounding, which a
+    difference quotient of step 1e-3 turns into ~1e-6 of the gradient: (ii) is held to 2e-5, (i) -- same arithmetic on both
+    sides -- to 2e-6.  The parameter tangents of the tables come from the complex-step trace (exact for ANY analytic
+    dependence on theta); a model with exp(theta) in a coefficient is checked against the analytic derivative."""
+    import sympy as sp
+    N, T = 15, 100
+    dt = 1e-2
+    ic = ss_models.benes_bernoulli(N)[3]
+    ys, _ = synth.benes_bernoulli_batch(1, T, dt, seed=8)
+
+    def model(P):
+        a, s, k = P[:, 0], P[:, 1], P[:, 2]
+        fns = moments.sde_cond_moments_tme(lambda x: a * sym.tanh(x), lambda _: s, dt, 2)
+        return fns[1], fns[3], (lambda y, x: stats.bernoulli_pmf(y, 1. / (1. + sym.exp(-k * x ** 3))))
+
+    theta = np.array([0.9, 1.1, 0.25])
+    nell, grad, fn = estimation.nell_and_grad_forward(model, theta, ic.cms, ic.mean, ys[0], return_first_nan=True)
+    assert fn == -1 and np.isfinite(nell) and np.all(np.isfinite(grad))
+
+    def dev_nell(P):
+        c, mu, lik = model(P)
+        return filtering.moment_filter_cms(c, mu, lik, ic.cms, ic.mean, np.repeat(ys, P.shape[0], axis=0))[2]
+
+    h = 1e-4
+    pts = np.repeat(theta[None], 7, axis=0)
+    for j in range(3):
+        pts[1 + 2 * j, j] += h
+        pts[2 + 2 * j, j] -= h
+    v = dev_nell(pts)
+    npt.assert_allclose(nell, v[0], rtol=1e-9)
+    fd = np.array([(v[1 + 2 * j] - v[2 + 2 * j]) / (2 * h) for j in range(3)])
+    npt.assert_allclose(grad, fd, rtol=2e-6, atol=2e-6 * np.abs(fd).max())
+
+    def oracle_nell(th):
+        a, s, k = th
+        f = tme_sympy.sde_cond_moments_tme_1d(lambda x: a * sp.tanh(x), lambda _: s, dt, 2, 2 * N)
+        lik = lambda y, x: om.bernoulli_pmf(y, 1. / (1. + np.exp(-k * x ** 3)))     # noqa: E731
+        return o.moment_filter_cms(f[1], f[3], lik, ic.cms, ic.mean, ys[0])[2]
+
+    npt.assert_allclose(nell, oracle_nell(theta), rtol=1e-8)
+    for j in range(3):
+        d = []
+        for hh in (2e-3, 1e-3):
+            tp, tm = theta.copy(), theta.copy()
+            tp[j] += hh
+            tm[j] -= hh
+            d.append((oracle_nell(tp) - oracle_nell(tm)) / (2 * hh))
+        rich = (4 * d[1] - d[0]) / 3
+        npt.assert_allclose(grad[j], rich, rtol=2e-5, atol=2e-5 * np.abs(grad).max())
+
+    # exact tangents for a non-polynomial dependence on the parameter: drift gain exp(theta_0)
+    def model_exp(P):
+        fns = moments.sde_cond_moments_tme(lambda x: np.exp(P[:, 0]) * sym.tanh(x), lambda _: 1.0, dt, 2)
+        return fns[1], fns[3], (lambda y, x: stats.bernoulli_pmf(y, 1. / (1. + sym.exp(-0.2 * x ** 3))))
+    t_c = estimation._tables_and_tangents(model_exp, np.array([0.3]), 'central', 1e-3, 'complex-step')
+    t_s = estimation._tables_and_tangents(model_exp, np.array([0.3]), 'central', 1e-3, 'stencil')
+    # d/d theta of a table entry that is a polynomial in a = exp(theta): a d/da -- compare with differentiating in a directly
+    def model_a(P):
+        fns = moments.sde_cond_moments_tme(lambda x: P[:, 0] * sym.tanh(x), lambda _: 1.0, dt, 2)
+        return fns[1], fns[3], (lambda y, x: stats.bernoulli_pmf(y, 1. / (1. + sym.exp(-0.2 * x ** 3))))
+    t_a = estimation._tables_and_tangents(model_a, np.array([np.exp(0.3)]), 'central', 1e-3, 'complex-step')
+    npt.assert_allclose(t_c[4], np.exp(0.3) * t_a[4], rtol=1e-14, atol=1e-300)
+    npt.assert_allclose(t_s[4], t_c[4], rtol=1e-9, atol=1e-14)               # (the stencil route, kept as the fallback)

@@ -267,3 +267,80 @@ def test_nan_measurement_poisons_the_nd_replicate_from_that_step():
     assert list(fn) == [-1, 13]
     assert np.all(np.isfinite(m[1, :13])) and np.all(np.isnan(m[1, 13:])) and np.isnan(nell[1]) and np.isfinite(nell[0])
     npt.assert_array_equal(m[0, :13], m[1, :13])
+
+
+def _bearing_only_model(N):
+    """/root/reference/examples/2d_bearing_only.ipynb cells 3-7: constant-velocity LTI model discretised exactly, Gaussian-sum
+    start, y_k = atan2(x_1, x_0) + sqrt(0.1) noise."""
+    import scipy.linalg
+    dt, T, xi = 0.01, 100, 0.1
+    A = np.array([[0., 1.], [0., 0.]])
+    Bm = np.array([[0., 0.], [0., 1.]])
+    # discretise_lti_sde (mfs/utils.py, Van Loan / Axelsson & Gustafsson 2015): F = expm(A dt), Q = int_0^dt e^{As} B B^T e^{A^T s} ds
+    blk = scipy.linalg.expm(np.block([[A, Bm @ Bm.T], [np.zeros((2, 2)), -A.T]]) * dt)
+    F = blk[:2, :2]
+    Q = blk[:2, 2:] @ F.T
+    means0 = np.array([[1., 0.], [1., 1.]])
+    covs0 = np.array([np.eye(2), np.eye(2)]) * 0.01
+    weights0 = np.array([0.7, 0.3])
+    rng = np.random.default_rng(999)
+    comp = rng.choice(2, p=weights0)
+    x = means0[comp] + 0.1 * rng.standard_normal(2)
+    cq = np.linalg.cholesky(Q)
+    ys = np.empty(T)
+    for k in range(T):
+        x = F @ x + cq @ rng.standard_normal(2)
+        ys[k] = np.arctan2(x[1], x[0]) + math.sqrt(xi) * rng.standard_normal()
+    return dt, T, xi, F, Q, means0, covs0, weights0, ys
+
+
+def test_bearing_only_example_runs_with_a_likelihood_of_both_components():
+    """examples/2d_bearing_only.ipynb cell 7: `norm.pdf(y, arctan2(x[1], x[0]), sqrt(xi))` is not a product of one-component
+    factors.  The reference evaluates any callable at the tensor-product nodes (mfs/multi_dims/filtering.py:263-275); the device
+    does the same on its eigen-node route (both K_k diagonalised; MFS_ND_UPDATE=grid integrates over the Chebyshev grid of the
+    Normal-closure prediction instead).  N = 4, T = 100 as in the notebook, against
+    oracle.multi_dims.moment_filter_nd_cms with the notebook's closures (Kan moments of N(F x - mean, Q)); 1e-6 on NLL and means."""
+    import os
+    from mfs_amd import sym, stats
+    from mfs_amd.utils import GaussianSumND
+    N = 4
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, T, xi, F, Q, means0, covs0, weights0, ys = _bearing_only_model(N)
+    gs = GaussianSumND.new(means0, covs0, weights0, mi)
+    ogs = omd.GaussianSumND.new(means0, covs0, weights0, mi)
+    fns = moments.cond_moments_linear_gaussian(F, Q, mi)
+
+    def pdf(y, x):
+        return stats.norm_pdf(y, sym.arctan2(x[1], x[0]), math.sqrt(xi))
+
+    cmss, means, nell = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pdf, ys, (mi, inds), gs.cms, gs.mean)
+
+    def o_cms(x, index, mean):       # the notebook's state_cond_central_moments
+        return np.array([[omd.raw_moments_mvn_kan(F @ xi_ - mean, Q, mi[i]) for i in index] for xi_ in x])
+
+    def o_pdf(y, x):
+        return np.exp(-0.5 * (y - np.arctan2(x[1], x[0])) ** 2 / xi) / math.sqrt(2 * math.pi * xi)
+
+    rc = omd.moment_filter_nd_cms((o_cms, 'index'), lambda x: x @ F.T, o_pdf, ys, (mi, inds), ogs.cms, ogs.mean)
+    assert np.isfinite(rc[2])
+    npt.assert_allclose(nell, rc[2], rtol=1e-6)
+    npt.assert_allclose(means, rc[1], rtol=1e-6, atol=1e-9)
+    from oracle import parity
+    assert parity.rel_err(cmss, rc[0], parity.natural_magnitude_nd(rc[0], mi)).max() <= 1e-6
+    # A/B: the Chebyshev grid of the prediction instead of the eigen-nodes (exact for polynomial integrands only: NLL and means
+    # hold 1e-6, the odd high moments lose digits to the interpolation of the likelihood)
+    os.environ['MFS_ND_UPDATE'] = 'grid'
+    try:
+        cm2, me2, ne2 = filtering.moment_filter_nd_cms((fns[1], 'index'), fns[3], pdf, ys, (mi, inds), gs.cms, gs.mean)
+    finally:
+        os.environ.pop('MFS_ND_UPDATE', None)
+    npt.assert_allclose(ne2, rc[2], rtol=1e-6)
+    npt.assert_allclose(me2, rc[1], rtol=1e-6, atol=1e-9)
+    assert parity.rel_err(cm2, rc[0], parity.natural_magnitude_nd(rc[0], mi)).max() <= 1e-3
+    # a joint factor with an operator-table transition is refused (its kernels hold no node tables)
+    from mfs_amd.multi_dims import ss_models as snd
+    dt2, _, _, gs2, drift, disp, _, _, _ = snd.prey_predator(mi)
+    tme = moments.sde_cond_moments_tme(drift, disp, dt2, 2)
+    with pytest.raises(Exception):
+        filtering.moment_filter_nd_cms((tme[1], 'multi-index'), tme[3], pdf, ys, (mi, inds), gs2.cms, gs2.mean)
