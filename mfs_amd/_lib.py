@@ -144,6 +144,9 @@ def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_pinned_live = [0]   # bytes of pinned pool memory currently held by result arrays of this process
+
+
 class _PinnedBlock:
     """Page-locked host memory from the library's pool; goes back to the pool when the last array viewing it dies."""
 
@@ -151,12 +154,15 @@ class _PinnedBlock:
         p = C.c_void_p()
         check(lib().mfs_host_alloc(C.byref(p), max(int(nbytes), 8), device))
         self.ptr = p
+        self.nbytes = int(nbytes)
+        _pinned_live[0] += self.nbytes
 
     def __del__(self):
         try:
             if self.ptr is not None and self.ptr.value:
                 lib().mfs_host_free(self.ptr)
                 self.ptr = None
+                _pinned_live[0] -= self.nbytes
         except Exception:
             pass
 
@@ -170,12 +176,27 @@ def pinned_empty(shape, dtype=np.float64, device=0):
         return np.empty(shape, dtype=dtype)
     dt = np.dtype(dtype)
     n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-    block = _PinnedBlock(n, device)
+    # page-locked memory cannot be swapped: beyond MFS_PINNED_BUDGET_MB (default 4096) of it held by live result arrays, and
+    # whenever the pinned allocation fails, the array is ordinary (pageable) NumPy memory -- slower copies, same results
+    budget = int(float(os.environ.get('MFS_PINNED_BUDGET_MB', '4096')) * (1 << 20))
+    if _pinned_live[0] + n > budget:
+        return np.empty(shape, dtype=dtype)
+    try:
+        block = _PinnedBlock(n, device)
+    except MfsError:
+        return np.empty(shape, dtype=dtype)
     # the array's base chain keeps `block` alive (and nothing points back, so reference counting alone frees it):
     # ndarray -> ctypes array -> (attribute) block
     buf = (C.c_char * max(n, 8)).from_address(block.ptr.value)
     buf._mfs_block = block
     return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+
+def pool_trim(device=0):
+    """Give the idle blocks of the library's device and pinned pools back to the runtime (mfs_pool_trim).  Result arrays
+    returned by the filters live in the pinned pool until they are garbage-collected; a sweep that keeps many of them can
+    call this after dropping them, or set MFS_PINNED_OUTPUTS=0 / MFS_PINNED_BUDGET_MB."""
+    check(lib().mfs_pool_trim(device))
 
 
 def pool_stats(device=0):

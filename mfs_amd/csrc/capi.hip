@@ -374,6 +374,14 @@ int mfs_plan_1d_run(mfs_plan_1d* p, const double* d_m0, int m0_batched, const do
 // How many T-chunks the host entry splits a run into when the moments are streamed out: the kernel of chunk k + 1 runs
 // while chunk k's slice of out_moments travels to the host (2-D copy: B rows of chunk x 2N doubles).  MFS_HOST_CHUNKS
 // overrides (1 = one launch, copies afterwards).
+// hipMemcpy2DAsync takes a pitch: a row of T x (moments per step) x 8 bytes beyond the runtime's limit (runs of ~1e6 steps and
+// more) would fail the whole call, so such runs go out in one linear copy instead (no copy / compute overlap)
+static bool pitch_ok(size_t pitch_bytes, int device) {
+    int maxp = 0;
+    if (hipDeviceGetAttribute(&maxp, hipDeviceAttributeMaxPitch, device) != hipSuccess || maxp <= 0) return pitch_bytes < ((size_t)1 << 31);
+    return pitch_bytes <= (size_t)maxp;
+}
+
 static int host_chunks(size_t moment_bytes, int T) {
     int n = (int)(moment_bytes / ((size_t)32 << 20));
     if (const char* e = getenv("MFS_HOST_CHUNKS")) n = atoi(e);
@@ -393,7 +401,7 @@ int mfs_filter_1d(const mfs_model_1d* model, int mode, int N, int T, int B, cons
     if (mode == MFS_MODE_SCALED && !scale0) return fail(MFS_EINVAL, "scale0 is required in scaled mode");
     const size_t M2 = 2 * (size_t)N + extra, nb = m0_batched ? B : 1;     // doubles per moment row
     const size_t mom_bytes = out_moments ? (size_t)B * T * M2 * 8 : 0;
-    const int nchunks = (B > 0 && T > 0 && !extra) ? host_chunks(mom_bytes, T) : 1;
+    const int nchunks = (B > 0 && T > 0 && !extra && pitch_ok((size_t)T * M2 * 8, device)) ? host_chunks(mom_bytes, T) : 1;
     const int chunk = (nchunks > 1) ? (T + nchunks - 1) / nchunks : 0;
     mfs_plan_1d* p = nullptr;
     if (int rc = mfs_plan_1d_create(&p, model, full_mode, N, T, B, stable, chunk, device)) return rc;
@@ -908,7 +916,7 @@ extern "C" int mfs_filter_nd(const mfs_model_nd* model, int mode, int N, int T, 
     // chunk x z doubles) on the copy stream while the kernel of chunk k + 1 runs; the per-replicate state crosses the
     // launches through a carry block, so the bits are those of the single launch
     const size_t mom_bytes = out_moments ? (size_t)B * T * Z * 8 : 0;
-    const int nchunks = (T > 0) ? host_chunks(mom_bytes, T) : 1;
+    const int nchunks = (T > 0 && pitch_ok((size_t)T * Z * 8, device)) ? host_chunks(mom_bytes, T) : 1;
     const int chunk = (nchunks > 1) ? (T + nchunks - 1) / nchunks : T;
     double* d_carry = nullptr;
     if (nchunks > 1) alloc(&d_carry, (size_t)B * mfs::g_nd_table[N].carry_doubles * 8);

@@ -261,7 +261,7 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
             const Dual<P> pn = (L0 - alpha[j]) * p1 - beta[j] * p0;
             p0 = p1; p1 = pn;
         }
-        w = drecip(acc);
+        w = drecip(acc * beta[0]);     // V[0, :]**2 of the normalised eigenvectors (quadtures.py:133): sums to 1 whatever m_0 is
     }
     const double qnan = __builtin_nan("");
     x_out = scale * L0 + mean;

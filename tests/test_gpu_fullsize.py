@@ -57,12 +57,25 @@ def test_config2_benes_bernoulli_full_size():
                                              np.array([0., 0., 0., 0.2]), want_moments=False)
     both = np.isfinite(cnell) & np.isfinite(nell[:nb])
     assert both.sum() > nb // 5
-    npt.assert_allclose(nell[:nb][both], cnell[both], rtol=2e-5)
-    # NaN onset: the two implementations agree exactly for most replicates and statistically overall
+    # (the C port is itself up to 6.9e-6 from exact arithmetic on the NLL of this batch -- tests/test_oracle_golden.py -- the
+    #  device 1e-10: the bulk agrees to 1e-8, the maximum is the port's own error)
+    rel = np.abs(nell[:nb][both] - cnell[both]) / np.abs(cnell[both])
+    assert np.quantile(rel, 0.9) <= 1e-8 and rel.max() <= 1e-5
+    # NaN onset: the two implementations agree exactly for most replicates and statistically overall (measured: 76 % within
+    # two steps; the two CPU implementations agree with each other on 71 %)
     c_first = np.where(np.isnan(cmeans).any(1), np.argmax(np.isnan(cmeans), 1), T)
     agree = np.mean(np.abs(c_first - live[:nb]) <= 2)
-    assert agree > 0.6
+    assert agree > 0.68
     assert abs(np.mean(c_first) - np.mean(live[:nb])) < 0.1 * T
+    # the worst replicates of THIS batch (largest device-vs-C-port deviations, tools/select_tails.py) against their
+    # exact-arithmetic trajectories: the device within 1e-6 on every quantity at every finite step
+    import os
+    from oracle import parity
+    e = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'filter_cfg2_exact_tails.npz'))
+    idx = e['central_idx']
+    assert np.array_equal(np.packbits(ys[idx].astype(np.uint8), axis=1), e['central_ys_bits'])
+    sc = parity.score_against_exact_tails(e, 'central', m[idx], means[idx], m[idx][..., 2], nell[idx])
+    assert max(sc['max'].values()) <= 1e-6, sc['max']
 
 
 @pytest.mark.parametrize('N', [5, 10, 15, 20, 25])
