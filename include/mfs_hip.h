@@ -61,7 +61,7 @@ extern "C" {
 #define MFS_LIK_POISSON_SOFTPLUS 1   /* rate = log(1 + exp(l0 x)), Poisson pmf(y; rate) (ss_models.py:80-84) */
 #define MFS_LIK_GAUSSIAN 2           /* y ~ N(l0 x + l1, l2) (l2 = variance) (convergence_mf.py:58-61) */
 #define MFS_LIK_BEARING_GAUSSIAN 3   /* N-D only, a factor of BOTH state components (fac_component = 2): y ~ N(atan2(x_1, x_0), l0),
-                                        l0 = variance (examples/2d_bearing_only.ipynb cell 7); Normal-closure transitions only */
+                                        l0 = variance (examples/2d_bearing_only.ipynb cell 7); not with TME-order-3 operator tables */
 
 #define MFS_MAX_N 32       /* quadrature order N (2N moments) */
 #define MFS_MAX_TERMS 8    /* K <= 2 * tme_order */
@@ -145,7 +145,8 @@ int mfs_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on
  *   mean0       [1] or [B] (same batching as m0); ignored in raw mode (may be NULL)
  *   scale0      likewise; scaled mode only
  *   ys          [B][T], measurements as doubles (Bernoulli y in {0., 1.})
- *   stable      0 = Cholesky; 1 = LDL^T completion (mfs/utils.py:495-538)
+ *   stable      0 = Cholesky; 1 = LDL^T completion (mfs/utils.py:495-538), on the same register-resident kernel (the completed
+ *               rule stays tridiagonal)
  *   out_moments [B][T][2N]   out_means [B][T] (NULL in raw mode)   out_scales [B][T] (scaled mode, else NULL)
  *   out_nell    [B]          out_first_nan [B]: first step whose outputs are non-finite, -1 if none (may be NULL)
  *   device      HIP device ordinal; stream: hipStream_t or NULL (a stream of the library's).  Returns after the

@@ -751,10 +751,10 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
             model->fac_n_par[f] > MFS_MAX_LIK || model->fac_component[f] < 0 || model->fac_component[f] > 2 ||
             (model->fac_component[f] == 2) != joint || model->fac_ycol[f] < 0 || model->fac_ycol[f] >= model->ny)
             return fail(MFS_EINVAL, "bad description of likelihood factor %d", f);
-        if (joint && (model->n_factors != 1 || model->trans_kind != MFS_ND_TRANS_GAUSSIAN))
-            return fail(MFS_EUNSUPPORTED, "a likelihood of both state components is integrated over the node set of a Normal-closure "
-                                          "prediction: one such factor, with sde_cond_moments_tme_normal / _euler_maruyama / "
-                                          "cond_moments_linear_gaussian");
+        if (joint && (model->n_factors != 1 || (model->trans_kind == MFS_ND_TRANS_OPERATOR && (model->n_terms > MFS_ND_TERMS || N > 6))))
+            return fail(MFS_EUNSUPPORTED, "a likelihood of both state components: one such factor, with a Normal-closure transition or "
+                                          "operator tables of TME order <= 2 at N <= 6 (the other kernels' tiles have no room for the "
+                                          "node tables)");
     }
     if (T < 0 || B < 0) return fail(MFS_EINVAL, "negative T or B");
     if (!multi_indices || !inds || !model->coef || !model->lik) return fail(MFS_EINVAL, "NULL buffer");

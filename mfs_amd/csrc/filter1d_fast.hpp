@@ -1,5 +1,6 @@
 // filter1d_fast.hpp -- register-resident 1-D moment-filter step for gfx950 (the default path; the LDS-tile kernel in
-// filter1d_kernel.hpp remains as the "dense" path: stable=True and cross-checks).
+// filter1d_kernel.hpp remains as the "dense" path: cross-checks, and the graded rules of stable=True).  stable=True and odd
+// moment counts run on the extended variant of this kernel (EXT template parameter: the completed rule in closed form).
 //
 // A filter is owned by G lanes (G = 8: half a DPP row; 16: one row; 32: two rows; 64), lane l holding row l of the
 // problem in VGPRs.  Cross-lane traffic is the DPP operand of the arithmetic instruction wherever the ISA allows it

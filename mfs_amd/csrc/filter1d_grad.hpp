@@ -155,48 +155,111 @@ __device__ __forceinline__ Dual<P> dlikelihood(const int kind, const double* __r
     }
 }
 
-// Gauss rule on duals: every lane runs the Chebyshev algorithm on the 2N dual moments in LDS; lane l < N then owns root l.
+// Gauss rule on duals.  The Chebyshev algorithm on the 2N dual moments runs LANE-PARALLEL in LDS (round 3): row k of the
+// sigma table is sigma_{k,l} = sigma_{k-1,l+1} - alpha_{k-1} sigma_{k-1,l} - beta_{k-1} sigma_{k-2,l}, l = k .. 2N-1-k, one or two
+// entries per lane, written over row k - 2 (which only the writing lane has read), one wavefront fence per row.  Round 2 kept
+// two full rows of duals redundantly in every lane's registers: 2 x 2N x (1 + P) doubles -- 480 registers at N = 15, P = 3,
+// i.e. 864 spilled at N = 15, P = 2.  alpha_k, beta_k (group-uniform duals) go to LDS as they are found; their value parts are
+// read back into registers for the eigenvalue search, their tangents stream through the two dual recurrences.  Lane l < N
+// then owns root l.
+//   qs: per-group scratch, [2][1 + P][2N] rows + [2][1 + P][N] coefficients.
 template <int N, int G, int P>
-__device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /* [1 + P][2N] */, const int l,
+__device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /* [1 + P][2N] */, double* __restrict__ qs, const int l,
                                                 const Dual<P>& mean, const Dual<P>& scale, Dual<P>& x_out, Dual<P>& w_out) {
-    constexpr int M2 = 2 * N;
-    Dual<P> alpha[N], beta[N];          // beta[0] = m_0
+    constexpr int M2 = 2 * N, DW = (1 + P) * M2;
+    double* X = qs;                      // row k - 1
+    double* Y = qs + DW;                 // row k - 2
+    double* AL = qs + 2 * DW;            // [1 + P][N]
+    double* BE = AL + (1 + P) * N;
+    auto dload = [&](const double* base, const int stride, const int n) {
+        Dual<P> r; r.v = base[n];
+#pragma unroll
+        for (int p = 0; p < P; ++p) r.d[p] = base[(1 + p) * stride + n];
+        return r;
+    };
+    auto dstore = [&](double* base, const int stride, const int n, const Dual<P>& c) {
+        base[n] = c.v;
+#pragma unroll
+        for (int p = 0; p < P; ++p) base[(1 + p) * stride + n] = c.d[p];
+    };
     bool poisoned = false;
-    {
-        Dual<P> prev[M2], cur[M2], piv_prev, sub_prev_over_piv;
+    constexpr bool kLds = (N > 8);      // registers hold the work arrays up to N = 8 (faster there: no LDS round trips per row; N = 10, P = 2 already spills 52)
+    Dual<P> ra[kLds ? 1 : N], rb[kLds ? 1 : N];      // alpha, beta as duals in registers (register form)
+    double av[N], bv[N];                              // their value parts (both forms)
+    if constexpr (!kLds) {
+        Dual<P> (&alpha)[N] = ra;
+        Dual<P> (&beta)[N] = rb;
+        {
+            Dual<P> prev[M2], cur[M2], piv_prev, sub_prev_over_piv;
 #pragma unroll
-        for (int n = 0; n < M2; ++n) {
-            cur[n].v = mom[n];
+            for (int n = 0; n < M2; ++n) {
+                cur[n].v = mom[n];
 #pragma unroll
-            for (int p = 0; p < P; ++p) cur[n].d[p] = mom[(1 + p) * M2 + n];
-            prev[n] = dconst<P>(0.0);
-        }
-        beta[0] = cur[0];
-        poisoned |= !(cur[0].v > 0.0);
-        alpha[0] = cur[1] / cur[0];
-        piv_prev = cur[0];
-        sub_prev_over_piv = alpha[0];
-        // sigma_{k, l}, l = k .. 2N - 1 - k, from rows k - 1 (cur) and k - 2 (prev), overwriting in place
-#pragma unroll
-        for (int k = 1; k < N; ++k) {
-#pragma unroll
-            for (int ll = k; ll < M2 - k; ++ll) {
-                const Dual<P> s = cur[ll + 1] - alpha[k - 1] * cur[ll] - ((k >= 2) ? beta[k - 1] * prev[ll] : dconst<P>(0.0));
-                prev[ll] = cur[ll];      // row k - 1 entry l, needed as "k - 2" in the next round
-                cur[ll] = s;
+                for (int p = 0; p < P; ++p) cur[n].d[p] = mom[(1 + p) * M2 + n];
+                prev[n] = dconst<P>(0.0);
             }
-            // (entries below k of cur / prev are stale and never read again)
-            const Dual<P> piv = cur[k];
-            poisoned |= !(piv.v > 0.0);
-            beta[k] = piv / piv_prev;
-            const Dual<P> ratio = cur[k + 1] / piv;
-            alpha[k] = ratio - sub_prev_over_piv;
-            piv_prev = piv;
-            sub_prev_over_piv = ratio;
+            beta[0] = cur[0];
+            poisoned |= !(cur[0].v > 0.0);
+            alpha[0] = cur[1] / cur[0];
+            piv_prev = cur[0];
+            sub_prev_over_piv = alpha[0];
+            // sigma_{k, l}, l = k .. 2N - 1 - k, from rows k - 1 (cur) and k - 2 (prev), overwriting in place
+#pragma unroll
+            for (int k = 1; k < N; ++k) {
+#pragma unroll
+                for (int ll = k; ll < M2 - k; ++ll) {
+                    const Dual<P> s = cur[ll + 1] - alpha[k - 1] * cur[ll] - ((k >= 2) ? beta[k - 1] * prev[ll] : dconst<P>(0.0));
+                    prev[ll] = cur[ll];      // row k - 1 entry l, needed as "k - 2" in the next round
+                    cur[ll] = s;
+                }
+                // (entries below k of cur / prev are stale and never read again)
+                const Dual<P> piv = cur[k];
+                poisoned |= !(piv.v > 0.0);
+                beta[k] = piv / piv_prev;
+                const Dual<P> ratio = cur[k + 1] / piv;
+                alpha[k] = ratio - sub_prev_over_piv;
+                piv_prev = piv;
+                sub_prev_over_piv = ratio;
+            }
         }
+
+#pragma unroll
+        for (int j = 0; j < N; ++j) { av[j] = ra[j].v; bv[j] = rb[j].v; }
+    } else {
+        for (int e = l; e < DW; e += G) { X[e] = mom[e]; Y[e] = 0.0; }
+        wave_sync();
+        {
+            const Dual<P> c0 = dload(X, M2, 0), c1 = dload(X, M2, 1);
+            poisoned |= !(c0.v > 0.0);
+            Dual<P> a_prev = c1 / c0, b_prev = c0, piv_prev = c0, sub_prev_over_piv = a_prev;
+            if (l == 0) { dstore(AL, N, 0, a_prev); dstore(BE, N, 0, c0); }      // beta[0] = m_0
+            for (int k = 1; k < N; ++k) {
+                for (int ll = k + l; ll < M2 - k; ll += G) {
+                    Dual<P> sg = dload(X, M2, ll + 1) - a_prev * dload(X, M2, ll);
+                    if (k >= 2) sg = sg - b_prev * dload(Y, M2, ll);
+                    dstore(Y, M2, ll, sg);
+                }
+                wave_sync();
+                double* t = X; X = Y; Y = t;
+                const Dual<P> piv = dload(X, M2, k), nxt = dload(X, M2, k + 1);
+                poisoned |= !(piv.v > 0.0);
+                b_prev = piv / piv_prev;
+                const Dual<P> ratio = nxt / piv;
+                a_prev = ratio - sub_prev_over_piv;
+                if (l == 0) { dstore(AL, N, k, a_prev); dstore(BE, N, k, b_prev); }
+                piv_prev = piv;
+                sub_prev_over_piv = ratio;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < N; ++j) { av[j] = AL[j]; bv[j] = BE[j]; }
     }
-    // NOTE on the in-place update above: cur[ll + 1] read at step ll is still row k - 1 (it is overwritten at step ll + 1),
-    // and prev[ll] read at step ll is row k - 2 (overwritten right after with row k - 1).
+    struct { double v; } alpha[N], beta[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { alpha[j].v = av[j]; beta[j].v = bv[j]; }
+    auto dalpha = [&](const int j) { if constexpr (kLds) return dload(AL, N, j); else return ra[j]; };
+    auto dbeta = [&](const int j) { if constexpr (kLds) return dload(BE, N, j); else return rb[j]; };
     // ---- root l by Sturm bisection (plain fp64), Gershgorin interval of the symmetric tridiagonal
     double lo = 1.79e308, hi = -1.79e308;
 #pragma unroll
@@ -237,11 +300,11 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
     // ---- tangent of the root: one dual evaluation of the recurrence at (lam, 0)
     Dual<P> L0 = dconst<P>(lam);
     {
-        Dual<P> p0 = dconst<P>(1.0), p1 = L0 - alpha[0];
+        Dual<P> p0 = dconst<P>(1.0), p1 = L0 - dalpha(0);
         double d0 = 0.0, d1 = 1.0;
 #pragma unroll
         for (int j = 1; j < N; ++j) {
-            const Dual<P> pn = (L0 - alpha[j]) * p1 - beta[j] * p0;
+            const Dual<P> pn = (L0 - dalpha(j)) * p1 - dbeta(j) * p0;
             const double dn = p1.v + (lam - alpha[j].v) * d1 - beta[j].v * d0;
             p0 = p1; p1 = pn; d0 = d1; d1 = dn;
         }
@@ -251,17 +314,19 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
     // ---- weight on duals: 1 / sum_j p_j(lam)^2 / h_j
     Dual<P> w;
     {
-        Dual<P> p0 = dconst<P>(1.0), p1 = L0 - alpha[0];
-        Dual<P> h = beta[0];
+        Dual<P> p0 = dconst<P>(1.0), p1 = L0 - dalpha(0);
+        const Dual<P> b0 = dbeta(0);
+        Dual<P> h = b0;
         Dual<P> acc = drecip(h);
 #pragma unroll
         for (int j = 1; j < N; ++j) {
-            h = h * beta[j];
+            const Dual<P> bj = dbeta(j);
+            h = h * bj;
             acc = acc + p1 * p1 / h;
-            const Dual<P> pn = (L0 - alpha[j]) * p1 - beta[j] * p0;
+            const Dual<P> pn = (L0 - dalpha(j)) * p1 - bj * p0;
             p0 = p1; p1 = pn;
         }
-        w = drecip(acc * beta[0]);     // V[0, :]**2 of the normalised eigenvectors (quadtures.py:133): sums to 1 whatever m_0 is
+        w = drecip(acc * b0);     // V[0, :]**2 of the normalised eigenvectors (quadtures.py:133): sums to 1 whatever m_0 is
     }
     const double qnan = __builtin_nan("");
     x_out = scale * L0 + mean;
@@ -270,7 +335,8 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
     return poisoned;
 }
 
-// One filter per G-lane group.  LDS per filter: dual moments [1 + P][2N], contribution table [G][1 + P][2N].
+// One filter per G-lane group.  LDS per filter: dual moments [1 + P][2N], contribution table [G][1 + P][2N], the quadrature's
+// scratch (two rows of the sigma table, alpha / beta).
 template <int N, int G, int P>
 __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGradArgs ga) {
     const Filter1dArgs& a = ga.f;
@@ -280,13 +346,15 @@ __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGrad
     const int grp = lane / G, l = lane - grp * G;
     const int b = blockIdx.x * FPW + grp;
     if (b >= a.B) return;
-    double* S = smem + (size_t)grp * (DW + G * DW + kCoefDoubles * (1 + P) + (MFS_MAX_LIK) * (1 + P));
+    constexpr int kQs = (N > 8) ? 2 * DW + 2 * (1 + P) * N : 0;     // (the LDS form of the Chebyshev algorithm only)
+    double* S = smem + (size_t)grp * (DW + G * DW + kCoefDoubles * (1 + P) + (MFS_MAX_LIK) * (1 + P) + kQs);
     double* mom = S;                              // [1 + P][2N]
     double* TAB = S + DW;                         // [G][1 + P][2N]
     double* coef = TAB + G * DW;                  // [n_rows][J + 1]
     double* dcoef = coef + kCoefDoubles;          // [P][n_rows][J + 1]
     double* lp = dcoef + kCoefDoubles * P;        // [n_lik]
     double* dlp = lp + MFS_MAX_LIK;               // [P][n_lik]
+    double* qs = dlp + MFS_MAX_LIK * P;           // quadrature scratch
     const int J1 = a.degree + 1, ncoef = a.n_rows * J1;
     {
         const double* src = a.coef + (a.coef_batched ? (size_t)b * ncoef : 0);
@@ -341,7 +409,7 @@ __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGrad
         // ---- prediction
         {
             Dual<P> x, w;
-            bad |= dual_quadrature<N, G, P>(mom, l, mean, scale, x, w);
+            bad |= dual_quadrature<N, G, P>(mom, qs, l, mean, scale, x, w);
             const Dual<P> u = (a.umap == MFS_U_TANH) ? dtanh(x) : x;
             Dual<P> c = dconst<P>(0.0), inv_sc = dconst<P>(1.0);
             if (a.trans_kind == MFS_TRANS_GAUSSIAN) {
@@ -392,7 +460,7 @@ __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGrad
         // ---- update
         {
             Dual<P> x, w;
-            bad |= dual_quadrature<N, G, P>(mom, l, mean, scale, x, w);
+            bad |= dual_quadrature<N, G, P>(mom, qs, l, mean, scale, x, w);
             const Dual<P> wl = w * dlikelihood<P>(a.lik_kind, lp, dlp, a.n_lik, y, x);
             const Dual<P> py = dgroup_sum<P, G>(wl);
             Dual<P> c = dconst<P>(0.0), inv_sc = dconst<P>(1.0);

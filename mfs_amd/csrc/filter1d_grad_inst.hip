@@ -11,7 +11,7 @@ Filter1dGradLaunch g_grad_table[kGradMaxN + 1][kGradMaxP + 1];
 template <int N, int P>
 int grad_lds_bytes() {
     constexpr int G = 16, DW = (1 + P) * 2 * N;
-    return (64 / G) * (DW + G * DW + kCoefDoubles * (1 + P) + MFS_MAX_LIK * (1 + P)) * 8;
+    return (64 / G) * (DW + G * DW + kCoefDoubles * (1 + P) + MFS_MAX_LIK * (1 + P) + ((N > 8) ? 2 * DW + 2 * (1 + P) * N : 0)) * 8;
 }
 
 template <int N, int P>

@@ -28,9 +28,13 @@
 //            of the same bilinear form (cheb_grid_rule_nd) -- exact, because NCP exceeds the integrands' degree per variable --
 //            and the Stein recursion runs per grid point, 16 moments at a time through a transposing DPP row reduction.  Only
 //            when NCP would not fit its table are the reference's s^2 eigen-nodes formed (both K_k diagonalised by cyclic Jacobi).
-// Front end of every rule: G = ms[inds[0]], H_k = ms[inds[1+k]] gathered from the LDS moment vector; Cholesky and both
-// triangular solves on one wave in registers (columns of L reach the other lanes as DPP operands after a lane-swap
-// duplication).  No MFMA: s <= 28, fp64, sequential.
+//   update, a likelihood of BOTH components (fac_component = 2; examples/2d_bearing_only.ipynb): Normal-closure kernels only --
+//            sum_ij W_ij l(y, x_ij) xi_0^a xi_1^b over the reference's own s^2 eigen-nodes (filtering.py:263-275).
+// Front end of every rule (front_nd): H_k = P_k G+ with G+ the Gram matrix extended by the degree-N monomials, so
+// K_k = R^-1 H_k R^-T = D^-1/2 L^-1 (P_k L+) D^1/2 -- one wave eliminates the rows of G+ in registers (L D L^T, columns of L
+// reaching the other lanes as DPP operands after a lane-swap duplication), then solves for the block-tridiagonal band of
+// K_k only (two short unit-triangular substitutions per column).  No H gathers, no index tables.  No MFMA: s <= 28, fp64,
+// sequential.
 #pragma once
 #include "filter1d_fast.hpp"
 
@@ -134,11 +138,14 @@ struct NdTile {
     static constexpr int LS = (NP > kNcpMax) ? NP : kNcpMax;           // stride of the two coordinate lists
     static constexpr int nWt = (R > kNcpMax * kNcpMax) ? R : kNcpMax * kNcpMax;
     static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] / [NCP][NCP] node weights (Normal closures)
-    static constexpr int oLam = oW + ((TK == 1) ? ((nWt + 1) & ~1) : 0); // [2][LS]
+    // a likelihood of both state components is integrated over the s^2 eigen-nodes: the kernels that take one hold the
+    // node weights [S][S] and the 16-row reduction table too (not the TME-order-3 tables, whose tile has no room left)
+    static constexpr bool kJoint = (TK == 1) || (TK == 0 && N <= 6);     // (N = 7 with operator tables: a second workgroup per CU matters more)
+    static constexpr int oLam = oW + ((TK == 1) ? ((nWt + 1) & ~1) : kJoint ? ((R + 1) & ~1) : 0); // [2][LS]
     static constexpr int ZB = (Z + 15) / 16;         // batches of 16 moments in the transposing reduction
     static constexpr int RW = 16 * ZB + 6;           // reduction row: moments (padded), flag, 5 scalar sums
     static constexpr int oRed = oLam + 2 * LS;       // [4 waves x 4 DPP rows][RW]
-    static constexpr int nRed = (TK == 1) ? 16 * RW : 16 * ZB + 16;   // operator path: Jacobi test scratch + the flag slot at [16 ZB]
+    static constexpr int nRed = kJoint ? 16 * RW : 16 * ZB + 16;   // (TK = 2: Jacobi test scratch + the flag slot at [16 ZB] only)
     static constexpr int kTerms = nd_terms<TK>(), kRows = nd_rows<TK>(), kMaxD = nd_maxd<TK>();
     static constexpr bool kOperator = (TK != 1);     // operator-table prediction (TK = 0, 2) or Normal closure (TK = 1)
     static constexpr int FFS = nd_kmax<TK>() + 1;    // falling-factorial table stride: k = 0 .. kmax
@@ -1461,7 +1468,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
     // which matrices an update diagonalises: the components a likelihood factor reads
     // (component 2 = a factor of BOTH components, e.g. a bearing measurement: no bilinear form of matrix functions exists for
     //  it; Normal-closure kernels integrate it over their node set -- Chebyshev grid or eigen-nodes -- like the prediction)
-    const bool joint = (TK == 1) && a.n_factors == 1 && a.fac_comp[0] == 2;
+    const bool joint = L::kJoint && a.n_factors == 1 && a.fac_comp[0] == 2;
     int lik_mask = 0;
     for (int f = 0; f < a.n_factors; ++f) lik_mask |= (a.fac_comp[f] < 2) ? (1 << a.fac_comp[f]) : 0;
     const int ubeg = (lik_mask & 1) ? 0 : 1, uend = (lik_mask & 2) ? 2 : 1;
@@ -1809,7 +1816,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 __syncthreads();
                 double c0 = 0.0, c1 = 0.0;
                 bool done_joint = false;
-                if constexpr (TK == 1) {
+                if constexpr (L::kJoint) {
                   if (joint) {
                     // ---- a likelihood of both components (filtering.py:263-275 evaluates measurement_cond_pdf at the tensor
                     //      nodes for ANY callable): sum_ij W_ij l(y, x_ij) xi_0^a xi_1^b over the node set of the Normal-closure
@@ -1820,11 +1827,16 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     //      on a Gershgorin box, which on the same example costs the odd high moments five digits (7e-5)
                     done_joint = true;
                     int Rn = R, Sn = S;
-                    if (a.joint_grid && ncp > 0) {
-                        cheb_grid_rule_nd<N, TK>(Sm, ncp);
-                        Rn = ncp * ncp; Sn = ncp;
-                        warm_mask = 0;
-                    } else {
+                    bool on_grid = false;
+                    if constexpr (TK == 1) {
+                        if (a.joint_grid && ncp > 0) {
+                            cheb_grid_rule_nd<N, TK>(Sm, ncp);
+                            Rn = ncp * ncp; Sn = ncp;
+                            warm_mask = 0;
+                            on_grid = true;
+                        }
+                    }
+                    if (!on_grid) {
                         jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
                         weights_nd<N, TK>(Sm);
                         warm_mask = poisoned ? 0 : 3;

@@ -338,9 +338,35 @@ def test_bearing_only_example_runs_with_a_likelihood_of_both_components():
     npt.assert_allclose(ne2, rc[2], rtol=1e-6)
     npt.assert_allclose(me2, rc[1], rtol=1e-6, atol=1e-9)
     assert parity.rel_err(cm2, rc[0], parity.natural_magnitude_nd(rc[0], mi)).max() <= 1e-3
-    # a joint factor with an operator-table transition is refused (its kernels hold no node tables)
+    # a joint factor with the TME-order-3 operator tables is refused (their tile has no room for the node tables)
     from mfs_amd.multi_dims import ss_models as snd
     dt2, _, _, gs2, drift, disp, _, _, _ = snd.prey_predator(mi)
-    tme = moments.sde_cond_moments_tme(drift, disp, dt2, 2)
+    tme = moments.sde_cond_moments_tme(drift, disp, dt2, 3)
     with pytest.raises(Exception):
         filtering.moment_filter_nd_cms((tme[1], 'multi-index'), tme[3], pdf, ys, (mi, inds), gs2.cms, gs2.mean)
+
+
+def test_bearing_likelihood_with_an_operator_table_transition():
+    """The same likelihood of both components with `sde_cond_moments_tme` (operator tables, 'multi-index' signature): the
+    prey--predator dynamics observed through a noisy bearing.  N = 3, T = 40 against the oracle at 1e-6."""
+    from mfs_amd import sym, stats
+    from mfs_amd.multi_dims import ss_models as snd
+    from oracle import parity
+    N, T = 3, 40
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, disp, _, _, _ = snd.prey_predator(mi)
+    _, _, ogs, odrift, odisp, _, _ = omd.prey_predator(mi)
+    fns = moments.sde_cond_moments_tme(drift, disp, dt, 2)
+    _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, 2, mi)
+    sd = 0.2
+    rng = np.random.default_rng(3)
+    ys = math.pi / 4 + sd * rng.standard_normal(T)              # the state hovers around (1, 1)
+    pdf = lambda y, x: stats.norm_pdf(y, sym.arctan2(x[1], x[0]), sd)                  # noqa: E731
+    o_pdf = lambda y, x: np.exp(-0.5 * ((y - np.arctan2(x[1], x[0])) / sd) ** 2) / (math.sqrt(2 * math.pi) * sd)   # noqa: E731
+    cmss, means, nell = filtering.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pdf, ys, (mi, inds), gs.cms, gs.mean)
+    rc = omd.moment_filter_nd_cms((ocms, 'multi-index'), omean, o_pdf, ys, (mi, inds), ogs.cms, ogs.mean)
+    assert np.isfinite(rc[2])
+    npt.assert_allclose(nell, rc[2], rtol=1e-6)
+    npt.assert_allclose(means, rc[1], rtol=1e-6, atol=1e-9)
+    assert parity.rel_err(cmss, rc[0], parity.natural_magnitude_nd(rc[0], mi)).max() <= 1e-6
