@@ -51,6 +51,63 @@ __device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / d
 #define ND_STAMP_BEGIN do {} while (0)
 #endif
 
+// Work is handed out by "thread id"; most phases of a step run on thread ids 0..63 or 0..127 only, i.e. on one or two of a
+// workgroup's four waves, and two workgroups share a CU.  MFS_ND_SIMD_ROLES=1 takes the id from the SIMD a wave sits on
+// rather than from its position in the workgroup -- role = (SIMD id + 2 * wave-slot parity) & 3, checked in the kernel
+// prologue to be a permutation of 0..3 -- so that the busy waves of the two co-resident workgroups never share a SIMD.
+// Measured (round 3): -9..12 % per step when every workgroup runs the SAME replicate (they are then
+// in lock step and the two busy waves issue the same instructions at the same time), 1 % on a real batch, whose
+// workgroups drift apart within a few steps.  Off by default.
+#ifndef MFS_ND_SIMD_ROLES
+#define MFS_ND_SIMD_ROLES 0
+#endif
+// (The empty volatile asm makes every call a fresh value to the optimiser.  Without it each inlined helper's thread-dependent
+//  LDS addresses are loop invariants of the time loop, get hoisted out of it by the dozen, do not fit in the register budget of
+//  two workgroups per CU and come back as scratch reloads -- a `s_waitcnt vmcnt(0)` in front of every phase -- where
+//  recomputing them is two or three integer instructions.)
+__device__ __forceinline__ int nd_tid(const double* misc) {
+#if MFS_ND_SIMD_ROLES
+    const int role = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(misc)[threadIdx.x >> 6]);
+    int t = role * 64 + (int)(threadIdx.x & 63);
+#else
+    (void)misc;
+    int t = threadIdx.x;
+#endif
+    asm volatile("" : "+v"(t));
+    return t;
+}
+// exponents (n0, n1) of moment zi in graded lexicographic order: zi = sd (sd + 1) / 2 + n0, sd = n0 + n1  (zi < 2^20)
+__device__ __forceinline__ void nd_exponents(const int zi, int& n0, int& n1) {
+    int sd = (int)((__builtin_sqrtf(8.0f * (float)zi + 1.0f) - 1.0f) * 0.5f);
+    sd += ((sd + 1) * (sd + 2) / 2 <= zi) ? 1 : 0;
+    sd -= (sd * (sd + 1) / 2 > zi) ? 1 : 0;
+    n0 = zi - sd * (sd + 1) / 2; n1 = sd - n0;
+}
+#ifdef MFS_ND_ROLE_DEBUG
+__device__ unsigned g_nd_role_fallbacks[2];
+#endif
+// Prologue of the kernel: settle the roles (two barriers; every thread of the workgroup must call it).
+__device__ __forceinline__ void nd_assign_roles(double* misc) {
+#if MFS_ND_SIMD_ROLES
+    int* roles = reinterpret_cast<int*>(misc);
+    const int w = threadIdx.x >> 6;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const int cand = (int)(((hw >> 4) + 2u * (hw & 1u)) & 3u);    // SIMD id, rotated by two on the odd wave slots
+    if ((threadIdx.x & 63) == 0) roles[w] = cand;
+    __syncthreads();
+    const unsigned seen = (1u << roles[0]) | (1u << roles[1]) | (1u << roles[2]) | (1u << roles[3]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && seen != 15u) roles[w] = w;
+#ifdef MFS_ND_ROLE_DEBUG
+    if (threadIdx.x == 0) { atomicAdd(&g_nd_role_fallbacks[0], seen != 15u ? 1u : 0u); atomicAdd(&g_nd_role_fallbacks[1], roles[0] != 0 ? 1u : 0u); }
+#endif
+    __syncthreads();
+#else
+    (void)misc;
+#endif
+}
+
 struct FilterNdArgs {
     int mode, T, B, stable;
     int t_begin, t_end;       // the steps this launch takes (a chunk of [0, T)); the state crosses launches through `carry`
@@ -190,13 +247,12 @@ struct NdTile {
     // operator terms (kappa, alpha, beta) inside the extents of their blocks, packed once per launch, and n!/(n-k)!
     static constexpr int kMaxTermWords = kTerms * kMaxD * kMaxD;       // 504 / 972 u32
     static constexpr int oTerms = oChW + 2 * nChW;           // [1 + kMaxTermWords] u32 (count first)
-    static constexpr int kTermChunk = 8;                     // terms a thread has in flight at once in the contraction
-    static constexpr int kTermGroups = (4 * Z <= 256) ? 4 : (3 * Z <= 256) ? 3 : (2 * Z <= 256) ? 2 : 1;   // threads per moment
-    static constexpr int kTermPad = kTermGroups * kTermChunk;   // the list is padded to a multiple of this with zero terms
-    static constexpr int oFf = oTerms + (kOperator ? (kMaxTermWords + kTermPad + 2) / 2 : 0);   // [P][FFS]
+    static constexpr int oFf = oTerms + (kOperator ? (kMaxTermWords + 2) / 2 : 0);   // [P][FFS]
     // gather indices of G, H_0, H_1 as u16 ([3][S][S]), when they fit next to the rest at two workgroups per CU: the
     // per-rule gather then makes no global-memory round trip
-    static constexpr int kDoubles0 = oFf + (kOperator ? P * FFS : 0);
+    // the non-empty rows of the operator table, one packed word each (the contraction walks them: see there), count in word 31
+    static constexpr int oRowTab = oFf + (kOperator ? P * FFS : 0);     // [32] u32
+    static constexpr int kDoubles0 = oRowTab + (kOperator ? 16 : 0);
     // scratch of the Jacobi warm-start products / first-order finish ([S][S]): the weight tile where it exists, else the
     // moment-array tiles (free while a Jacobi runs)
     // Chebyshev-grid rule of a Normal closure: the transform table D[a][p] = (2 - [a = 0]) / NCP cos(pi a (p + 1/2) / NCP), the
@@ -370,7 +426,7 @@ template <int N, int TK>
 __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
     double* mom = Sm + L::oMom;
     double* A = Sm + L::oA;
     double* K = Sm + L::oK;
@@ -637,7 +693,7 @@ template <int N, int TK>
 __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int mend, const int warm_mask) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
     double* A = Sm + L::oA;
     double* K = Sm + L::oK;
     double* V = Sm + L::oV;
@@ -727,7 +783,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
         dia = Sm[L::oRed + 1] + Sm[L::oRed + 4] + Sm[L::oRed + 7] + Sm[L::oRed + 10];
         xsq = Sm[L::oRed + 2] + Sm[L::oRed + 5] + Sm[L::oRed + 8] + Sm[L::oRed + 11];
 #ifdef MFS_ND_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) {
             int bin = (off > 0.0 && dia > 0.0) ? (int)(-log10(off / dia)) : 39;
             bin = bin < 0 ? 0 : bin > 39 ? 39 : bin;
             g_nd_hist[sweep < 8 ? sweep : 7][bin] += 1;
@@ -857,7 +913,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
         prev_off = off;
         }
 #ifdef MFS_ND_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[8] += 1;
+        if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[8] += 1;
 #endif
 
         for (int r = 0; r < NP - 1; ++r) {
@@ -985,7 +1041,7 @@ template <int N, int TK>
 __device__ void weights_nd(double* __restrict__ Sm) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
     const double* K = Sm + L::oK;
     const double* V = Sm + L::oV;
     ND_STAMP_BEGIN;
@@ -1062,7 +1118,7 @@ template <int N, int TK>
 __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask, const double d0, const double d1) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW;
-    const int tid = threadIdx.x;
+    const int tid = nd_tid(Sm + L::oMisc);
     if (tid < 128 && ((wmask >> (tid >> 6)) & 1)) {
         const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
         const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
@@ -1082,33 +1138,72 @@ __device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wma
 // M[p][q] = fac sc0^p sc1^q PK[0][p] . PK[1][q] for p, q < npow with p + q <= maxdeg (the only entries any later stage
 // reads; the rest are zeroed): the moments sum_ij W_ij xi0_i^p xi1_j^q of the rule about its own centre
 // (xi = x - mean = scale * lambda).
+// sum_{al < EA, be < EB} q[al EB + be] Mw[al MLD + be], at most a dozen terms' reads in flight at a time
+template <int EA, int EB, int MLD>
+__device__ __forceinline__ double window_sum_nd(const double* __restrict__ q, const double* __restrict__ Mw) {
+    constexpr int RG = (12 / EB > 0) ? 12 / EB : 1;      // block rows per batch
+    double s0 = 0.0, s1 = 0.0;
+    static_for<0, (EA + RG - 1) / RG>([&](auto Gc) {
+        constexpr int a0 = Gc * RG, a1 = (a0 + RG < EA) ? a0 + RG : EA, CNT = (a1 - a0) * EB;
+        double qv[CNT], mv[CNT];
+        static_for<0, CNT>([&](auto Tc) {
+            constexpr int al = a0 + Tc / EB, be = Tc % EB;
+            qv[Tc] = q[al * EB + be]; mv[Tc] = Mw[al * MLD + be];
+        });
+        static_for<0, CNT>([&](auto Tc) {
+            if constexpr (Tc % 2 == 0) s0 = fma(qv[Tc], mv[Tc], s0); else s1 = fma(qv[Tc], mv[Tc], s1);
+        });
+    });
+    return s0 + s1;
+}
+__device__ __forceinline__ double ipow32(double x, int n) {    // x^n, 0 <= n < 32
+    double r = 1.0;
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit) { if (n & 1) r *= x; x *= x; n >>= 1; }
+    return r;
+}
+// (This Gram product of the two Krylov families is the one GEMM-shaped piece of a step -- [npow x S] . [S x npow] -- and goes
+//  through the fp64 matrix core: v_mfma_f64_16x16x4_f64, one 16 x 16 tile of M per wave, ceil(S / 4) instructions, operands
+//  A[i = lane & 15][k = lane >> 4] = PK[0][16 ti + i][4 s + k], B[k][j] = PK[1][16 tj + j][4 s + k], results
+//  D[(lane >> 4) + 4 r][lane & 15] in register r.  As one thread per entry with 2 S LDS reads each it took 2.5 k cycles
+//  per call, two calls per step.)
 template <int N, int TK>
 __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const int maxdeg, const double sc0,
                                     const double sc1, const double fac) {
     using L = NdTile<N, TK>;
-    constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD;
-    const double* p0 = Sm + L::oPK;
-    const double* p1 = Sm + L::oPK + NPW * NP;
+    constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD, KS = (S + 3) / 4;
+    static_assert(NPW <= 32, "at most 2 x 2 tiles of 16 x 16");
+    typedef double d4 __attribute__((ext_vector_type(4)));
     double* M = Sm + L::oM;
-    for (int e = threadIdx.x; e < npow * npow; e += blockDim.x) {
-        const int p = e / npow, q = e - p * npow;
-        double v = 0.0;
-        if (p + q <= maxdeg) {
-            const double* u = p0 + p * NP;
-            const double* w = p1 + q * NP;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            static_for<0, S>([&](auto Jc) {
-                constexpr int j = Jc;
-                if constexpr (j % 3 == 0) a0 = fma(u[j], w[j], a0);
-                else if constexpr (j % 3 == 1) a1 = fma(u[j], w[j], a1);
-                else a2 = fma(u[j], w[j], a2);
-            });
-            double f = fac;
-            for (int k = 0; k < p; ++k) f *= sc0;
-            for (int k = 0; k < q; ++k) f *= sc1;
-            v = ((a0 + a1) + a2) * f;
+    const int tid = nd_tid(Sm + L::oMisc);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    const int side = (npow + 15) >> 4;
+    for (int tile = w; tile < side * side; tile += 4) {
+        const int ti = tile / side, tj = tile - ti * side;
+        const double* ua = Sm + L::oPK + min(16 * ti + r16, NPW - 1) * NP;
+        const double* ub = Sm + L::oPK + NPW * NP + min(16 * tj + r16, NPW - 1) * NP;
+        double av[KS], bv[KS];
+        static_for<0, KS>([&](auto Sc) {
+            constexpr int j0 = 4 * Sc;
+            if constexpr (j0 + 3 < S) { av[Sc] = ua[j0 + kk]; bv[Sc] = ub[j0 + kk]; }
+            else {      // the last slice runs past the vectors: a zero on one side, a valid (finite) entry on the other
+                const int jc = min(j0 + kk, S - 1);
+                const double x = ua[jc];
+                av[Sc] = (j0 + kk < S) ? x : 0.0; bv[Sc] = ub[jc];
+            }
+        });
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        static_for<0, KS>([&](auto Sc) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[Sc], bv[Sc], acc, 0, 0, 0); });
+        const int q = 16 * tj + r16, pb = 16 * ti + kk;
+        double fq = fac, f0 = 1.0, f4 = 1.0;
+        if (sc0 != 1.0 || sc1 != 1.0) { fq *= ipow32(sc1, q); f0 = ipow32(sc0, pb); f4 = (sc0 * sc0) * (sc0 * sc0); }
+        fq *= f0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pp = pb + 4 * r;
+            if (pp < npow && q < npow) M[pp * MLD + q] = (pp + q <= maxdeg) ? acc[r] * fq : 0.0;
+            fq *= f4;
         }
-        M[p * MLD + q] = v;
     }
 }
 
@@ -1124,15 +1219,15 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
     double* M2 = Sm + L::oM2;
     const double* bin = Sm + L::oBin;
     double* pw = Sm + L::oPw;      // [2][NPW]
-    if (threadIdx.x < 2) {
-        const double d = threadIdx.x ? -d1 : -d0;
+    if (nd_tid(Sm + L::oMisc) < 2) {
+        const double d = nd_tid(Sm + L::oMisc) ? -d1 : -d0;
         double v = 1.0;
-        for (int k = 0; k < NPW; ++k) { pw[threadIdx.x * NPW + k] = v; v *= d; }
+        for (int k = 0; k < NPW; ++k) { pw[nd_tid(Sm + L::oMisc) * NPW + k] = v; v *= d; }
     }
     __syncthreads();
     // Fixed trip count NJ >= nout with every LDS read of an entry issued before any arithmetic (terms j > a are masked by
     // a select on the loaded value, not by a branch): a loop to the true bound a was one dependent LDS round trip per term.
-    for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q], q <= maxdeg - a
+    for (int e = nd_tid(Sm + L::oMisc); e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q], q <= maxdeg - a
         const int a = e / nout, q = e - a * nout;
         if (a + q > maxdeg) continue;
         double c[NJ], v[NJ];
@@ -1150,7 +1245,7 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
         M2[a * MLD + q] = acc0 + acc1;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
+    for (int e = nd_tid(Sm + L::oMisc); e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
         const int a = e / nout, b = e - a * nout;
         if (a + b > maxdeg) continue;
         double c[NJ], v[NJ];
@@ -1187,7 +1282,7 @@ __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const 
                                const double scale0, const double scale1) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW, NCH = L::NCH;
-    const int tid = threadIdx.x;
+    const int tid = nd_tid(Sm + L::oMisc);
     if (tid >= 128) return;
     const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
     const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
@@ -1266,7 +1361,7 @@ __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const 
         if (lane < S) pk[lane] = h;
         ND_STAMP(18);
 #ifdef MFS_ND_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[20] += deg;
+        if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[20] += deg;
 #endif
         // ---- K h as well (K u = half Khat u + mid u): with h it gives p_y and the posterior mean, about which the caller
         //      then takes the powers
@@ -1294,7 +1389,7 @@ template <int N, int TK>
 __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, LS = L::LS, NCM = L::kNcpMax;
-    const int tid = threadIdx.x;
+    const int tid = nd_tid(Sm + L::oMisc);
     double* U = Sm + L::oU;              // [2][ncp][NP]
     const double* Dt = Sm + L::oChD;     // [a][p], row stride ncp
     if (tid < 128) {
@@ -1389,7 +1484,8 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
     constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = L::kMaxD * L::kMaxD;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
-    const int tid = threadIdx.x, b = blockIdx.x;
+    nd_assign_roles(Sm + L::oMisc);
+    const int tid = nd_tid(Sm + L::oMisc), b = blockIdx.x;
     const bool scaled = a.mode == MFS_MODE_SCALED;
     const bool raw = a.mode == MFS_MODE_RAW;
     double* mom = Sm + L::oMom;
@@ -1435,10 +1531,18 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                                       ((unsigned)ea << 12) | ((unsigned)eb << 15) | ((unsigned)(k * DD6 + al * L::kMaxD + be) << 18);
             }
             tw[0] = n;
-            // pad to whole chunks with terms that read the always-zero slot of the re-centred table
-            for (int q = 0; q < L::kTermPad; ++q) tw[1 + n + q] = (unsigned)(L::kTerms * DD6) << 18;
+            // row words: k0 | k1 << 3 | ea << 6 | eb << 9 | (index of the row's first term) << 12 | (wave pair that takes it) << 22
+            unsigned* rw = reinterpret_cast<unsigned*>(Sm + L::oRowTab);
+            unsigned nr = 0, first = 0;
+            for (int k = 0; k < a.n_terms_used && k < L::kTerms; ++k) {
+                const unsigned ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
+                if (ea * eb == 0) continue;
+                rw[nr++] = (unsigned)kKap0[k] | ((unsigned)kKap1[k] << 3) | (ea << 6) | (eb << 9) | (first << 12) | ((2 * first >= n ? 1u : 0u) << 22);
+                first += ea * eb;
+            }
+            for (unsigned q = nr; q < 31; ++q) rw[q] = 0;
+            rw[31] = nr;
         }
-        if (tid == 0) Sm[L::oQs + L::kTerms * DD6] = 0.0;
         for (int e = tid; e < P * L::FFS; e += 256) Sm[L::oFf + e] = ffact(e / L::FFS, e % L::FFS) * ((e % L::FFS <= e / L::FFS) ? 1.0 : 0.0);
     }
     if (tid < 8) {
@@ -1509,6 +1613,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
             // largest piece of straight-line code in the kernel).
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
+            const int tid = nd_tid(Sm + L::oMisc);     // (a fresh value per half-step: see nd_tid)
             const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
             bad = bad || poisoned;
             // =========================================================================================================
@@ -1609,7 +1714,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                                 acc = fma(bin[i * NPW + al] * pi, rsum, acc);
                                 pi *= c0;
                             }
-                            qs[qi] = acc;
+                            qs[e] = acc;        // (term order: the contraction walks the list front to back)
                         }
                     }
                     __syncthreads();
@@ -1618,59 +1723,49 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1, 1.0);
                     __syncthreads();
                     ND_STAMP(14);
-                    // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)],
-                    //      the kappa terms of a moment spread over four threads (partial sums through the free M2 tile)
+                    // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)].
+                    //      Lane = moment n (two waves cover them), the term list split between the two wave pairs at a row
+                    //      boundary: the walk over (kappa, al, be) is then the same for every lane of a wave -- the row's
+                    //      extents, the term index and the Q' address are scalar, the falling factorials are read once per
+                    //      row and the window of M is one base address per row plus immediate offsets.  Per term that leaves
+                    //      two LDS reads and one multiply-add (as one (kappa, al, be) term at a time per thread, each decoded from
+                    //      its packed word -- about 25 instructions per term -- this was 7.2 k cycles per step).
                     {
-                        double* part = Sm + L::oM2;      // [groups][Z]
-                        constexpr int GR = L::kTermGroups, CH = L::kTermChunk;
-                        static_assert(GR * Z <= NPW * MLD, "partial sums must fit in the M2 tile");
-                        const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
-                        const int nt = (int)tw[0];
+                        double* part = Sm + L::oM2;      // [2][Z]
+                        static_assert(2 * Z <= NPW * MLD && Z <= 128, "partial sums must fit in the M2 tile");
                         const double* ff = Sm + L::oFf;
-                        if (tid < GR * Z) {
-                            const int grp = tid / Z, zi = tid - grp * Z;
-                            int sd = 0;
-                            while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                            const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                            double v0 = (grp == 0) ? M[n0 * MLD + n1] : 0.0, v1 = 0.0;
-                            const double* f0 = ff + n0 * L::FFS;
-                            const double* f1 = ff + n1 * L::FFS;
-                            // A chunk of CH terms at a time, every LDS read of the chunk issued before any arithmetic: the
-                            // term words first, then the four operands of each term (the one-term-at-a-time loop was two
-                            // dependent LDS round trips per term, 18 k cycles per step).  A term with kappa > n has a zero
-                            // falling factorial: its M index is clamped, not branched on; the list is padded with zero terms.
-                            for (int t0 = grp * CH; t0 < nt; t0 += GR * CH) {
-                                unsigned w[CH];
-                                static_for<0, CH>([&](auto Jc) { w[Jc] = tw[1 + t0 + Jc]; });
-                                double fa[CH], fb[CH], q[CH], mv[CH];
-                                static_for<0, CH>([&](auto Jc) {
-                                    const unsigned wj = w[Jc];
-                                    const int k0 = wj & 7, k1 = (wj >> 3) & 7, al = (wj >> 6) & 7, be = (wj >> 9) & 7;
-                                    const int r0 = max(n0 - k0, 0) + al, r1 = max(n1 - k1, 0) + be;
-                                    fa[Jc] = f0[k0]; fb[Jc] = f1[k1]; q[Jc] = qs[wj >> 18]; mv[Jc] = M[r0 * MLD + r1];
+                        int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
+                        const int pair = __builtin_amdgcn_readfirstlane(tid >> 7);
+                        static_assert(L::kTerms < 31, "row words live in the lanes of one register");
+                        const unsigned myrow = reinterpret_cast<const unsigned*>(Sm + L::oRowTab)[tid & 31];
+                        const int nrows = __builtin_amdgcn_readlane(myrow, 31);
+                        const double* f0 = ff + zn0 * L::FFS;
+                        const double* f1 = ff + zn1 * L::FFS;
+                        double v = 0.0;
+                        for (int k = 0; k < nrows; ++k) {
+                            const unsigned rwd = __builtin_amdgcn_readlane(myrow, k);
+                            if ((int)(rwd >> 22) != pair) continue;
+                            const int k0 = rwd & 7, k1 = (rwd >> 3) & 7, ea = (rwd >> 6) & 7, eb = (rwd >> 9) & 7, first = (rwd >> 12) & 1023;
+                            const double fa = f0[k0], fb = f1[k1];        // (zero where kappa exceeds n: the window's base is clamped, not branched on)
+                            const double* Mw = M + max(zn0 - k0, 0) * MLD + max(zn1 - k1, 0);
+                            const double* q = qs + first;
+                            // the block's extents select a fully unrolled window sum (compile-time offsets, every LDS read of
+                            // the window in flight before the first multiply-add: with run-time trip counts each term was
+                            // its own read - wait - multiply-add round trip)
+                            double in = 0.0;
+                            static_for<1, L::kMaxD + 1>([&](auto Ea) {
+                                if (ea == Ea) static_for<1, L::kMaxD + 1>([&](auto Eb) {
+                                    if (eb == Eb) in = window_sum_nd<Ea, Eb, MLD>(q, Mw);
                                 });
-                                static_for<0, CH>([&](auto Jc) {
-                                    if constexpr (Jc % 2 == 0) v0 = fma(fa[Jc] * fb[Jc] * q[Jc], mv[Jc], v0);
-                                    else v1 = fma(fa[Jc] * fb[Jc] * q[Jc], mv[Jc], v1);
-                                });
-                            }
-                            part[tid] = v0 + v1;
+                            });
+                            v = fma(fa * fb, in, v);
                         }
+                        if ((tid & 127) < Z) part[pair * Z + (tid & 127)] = v;
                         __syncthreads();
-                        for (int zi = tid; zi < Z; zi += 256) {
-                            int sd = 0;
-                            while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                            const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                            double v = part[zi];
-                            static_for<1, L::kTermGroups>([&](auto Gc) { v += part[Gc * Z + zi]; });
-                            if (scaled) {
-                                const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
-                                double f = 1.0;
-                                for (int q = 0; q < n0; ++q) f *= i0;
-                                for (int q = 0; q < n1; ++q) f *= i1;
-                                v *= f;
-                            }
-                            mom[zi] = v;
+                        if (tid < Z) {
+                            double v = (part[tid] + part[Z + tid]) + M[zn0 * MLD + zn1];
+                            if (scaled) v *= ipow32(1.0 / ns0, zn0) * ipow32(1.0 / ns1, zn1);
+                            mom[tid] = v;
                             if (!finite(v)) red[16 * ZB] = 1.0;
                         }
                     }
@@ -1776,10 +1871,9 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         });
                     }
                     __syncthreads();
-                    for (int zi = tid; zi < Z; zi += 256) {
-                        int sd = 0;
-                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                    if (tid < Z) {
+                        int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
+                        const int zi = tid, n0 = zn0, n1 = zn1;
                         const int e = n0 * P - n0 * (n0 - 1) / 2 + n1;    // predictions of a Normal closure emit row by row
                         double v = 0.0;
 #pragma unroll
@@ -1875,10 +1969,9 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         });
                     }
                     __syncthreads();
-                    for (int zi = tid; zi < Z; zi += 256) {          // the sums about the OLD mean into the moment array
-                        int sd = 0;
-                        while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                        const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
+                    if (tid < Z) {          // the sums about the OLD mean into the moment array
+                        int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
+                        const int n0 = zn0, n1 = zn1;
                         const int e = n0 * P - n0 * (n0 - 1) / 2 + n1;
                         double v = 0.0;
 #pragma unroll
@@ -1978,18 +2071,11 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 }   // (separable likelihood)
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
-                for (int zi = tid; zi < Z; zi += 256) {
-                    int sd = 0;
-                    while ((sd + 1) * (sd + 2) / 2 <= zi) ++sd;
-                    const int n0 = zi - sd * (sd + 1) / 2, n1 = sd - n0;
-                    double v = M[n0 * MLD + n1];
-                    if (scaled) {
-                        const double i0 = 1.0 / ns0, i1 = 1.0 / ns1;
-                        double f = 1.0;
-                        for (int q = 0; q < n0; ++q) f *= i0;
-                        for (int q = 0; q < n1; ++q) f *= i1;
-                        v *= f;
-                    }
+                if (tid < Z) {
+                    const int zi = tid;
+                    int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
+                    double v = M[zn0 * MLD + zn1];
+                    if (scaled) v *= ipow32(1.0 / ns0, zn0) * ipow32(1.0 / ns1, zn1);
                     mom[zi] = v;
                     if (!finite(v)) red[16 * ZB] = 1.0;
                 }
@@ -2001,7 +2087,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 if (tid == 0) red[16 * ZB] = 0.0;
                 ND_STAMP(7);
 #ifdef MFS_ND_STAMPS
-                if (blockIdx.x == 0 && threadIdx.x == 0) g_nd_stamps[9] += 1;
+                if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[9] += 1;
 #endif
             }
             }   // half

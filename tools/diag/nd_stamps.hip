@@ -1,5 +1,7 @@
 // diagnostic: run the N-D kernel with phase stamps on a synthetic well-conditioned problem read from a .bin dump
+#ifndef NO_STAMPS
 #define MFS_ND_STAMPS
+#endif
 #include "../../mfs_amd/csrc/filternd_kernel.hpp"
 #include <cstdio>
 #include <vector>
@@ -40,9 +42,16 @@ int run(int argc, char** argv) {
         for (int it = 0; it < 3; ++it) hipLaunchKernelGGL((filternd_kernel<N, TK>), dim3(B), dim3(256), lds, 0, a);
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        printf("B = %d, T = %d: %.3f ms per pass (diagnostic build, stamps on), lds %d B\n", B, T, ms / 3, lds);
+        printf("B = %d, T = %d: %.3f ms per pass (diagnostic build), lds %d B\n", B, T, ms / 3, lds);
+#ifdef MFS_ND_ROLE_DEBUG
+        unsigned fb[2]; hipMemcpyFromSymbol(fb, HIP_SYMBOL(g_nd_role_fallbacks), sizeof(fb));
+        printf("role fallbacks %u, workgroups whose wave 0 is not role 0: %u (of %d launched)\n", fb[0], fb[1], 4 * B);
+#endif
         return 0;
     }
+#ifndef MFS_ND_STAMPS
+    printf("(built without stamps: timing runs only)\n"); return 0;
+#else
     unsigned long long st[24]; hipMemcpyFromSymbol(st, HIP_SYMBOL(g_nd_stamps), sizeof(st));
     const char* names[] = {"gather (x2)", "cholesky (x2)", "trsm+sym (x2)", "warm-start matmuls / Chebyshev-grid rule", "jacobi sweeps", "weights", "bilinear predict", "bilinear update"};
     double tot = 0; for (int i = 0; i < 8; ++i) tot += st[i];
@@ -64,5 +73,6 @@ int run(int argc, char** argv) {
     }
     std::vector<double> nell(B); hipMemcpy(nell.data(), dnell, B * 8, hipMemcpyDeviceToHost); printf("nell[0] = %.10f\n", nell[0]);
     return 0;
+#endif
 }
 int main(int argc, char** argv) { return (argc > 2 && argv[2][0] == '1') ? run<1>(argc, argv) : run<0>(argc, argv); }
