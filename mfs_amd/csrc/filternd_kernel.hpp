@@ -342,6 +342,29 @@ __device__ __forceinline__ double poly2d(const double* __restrict__ c, const int
     return acc;
 }
 
+// The same sum over the whole DD x DD block (entries outside a block's true extents are zero in the table), every
+// coefficient read issued before the first multiply-add: with run-time extents the nested Horner loops above are one
+// dependent LDS round trip per coefficient, ~900 cycles per polynomial, and a Normal-closure prediction evaluates five
+// per node.
+template <int DDc>
+__device__ __forceinline__ double poly2d_full(const double* __restrict__ c, const double x0, const double x1) {
+    double cv[DDc * DDc];
+    static_for<0, DDc * DDc>([&](auto Tc) { cv[Tc] = c[Tc]; });
+    double acc = 0.0;
+    static_for<0, DDc>([&](auto Ar) {
+        constexpr int a = DDc - 1 - Ar;
+        double row = cv[a * DDc + DDc - 1];
+        static_for<0, DDc - 1>([&](auto Bc) { constexpr int b = DDc - 2 - Bc; row = fma(row, x1, cv[a * DDc + b]); });
+        acc = fma(acc, x0, row);
+    });
+    return acc;
+}
+// f(integral_constant<D>) for the block extent D of this launch (1 <= D <= DMAX): one uniform branch
+template <int DMAX, class F>
+__device__ __forceinline__ void dispatch_extent(const int D, F&& f) {
+    static_for<1, DMAX + 1>([&](auto Dc) { if (D == Dc) f(Dc); });
+}
+
 // the Bernoulli-logistic likelihood (mfs/multi_dims/ss_models.py:63-67) with the in-line exponential; other kinds through
 // the generic routine
 __device__ __forceinline__ double likelihood_nd(const int kind, const double* __restrict__ lp, const double y,
@@ -1278,7 +1301,7 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
 // Leaves PK[k][0] = h_k, PK[k][1] = K_k h_k.  No block barrier inside.
 template <int N, int TK>
 __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const int lik_mask,
-                          const double* __restrict__ ysrow, const double mean0, const double mean1,
+                          const double (&yv)[MFS_ND_MAX_FACTORS], const double mean0, const double mean1,
                                const double scale0, const double scale1) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW, NCH = L::NCH;
@@ -1318,8 +1341,9 @@ __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const 
             const double lam = fma(half, Sm[L::oChX + j], mid);
             const double x = fma(lam, w ? scale1 : scale0, w ? mean1 : mean0);
             double f = 1.0;
-            for (int q = 0; q < a.n_factors; ++q)
-                if (a.fac_comp[q] == w) f *= likelihood_nd(a.fac_kind[q], Sm + L::oLik + 4 * q, ysrow[a.fac_ycol[q]], x);
+            static_for<0, MFS_ND_MAX_FACTORS>([&](auto Qc) {      // (loaded by the caller)
+                if (Qc < a.n_factors && a.fac_comp[Qc] == w) f *= likelihood_nd(a.fac_kind[Qc], Sm + L::oLik + 4 * Qc, yv[Qc], x);
+            });
             if (lane < NCH) vbuf[lane] = f;      // (the vector buffers double as the sample buffer)
         }
         wave_sync();
@@ -1424,49 +1448,66 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
         if (lane < ncp) Sm[L::oLam + w * LS + lane] = fma(half, Sm[L::oChG + lane], mid);
     }
     __syncthreads();
-    // cardinal vectors u_p = sum_a D[a][p] t_a on all threads, into the tiles of G, K_0, K_1, V_0, V_1 (the matrices have done
-    // their work for this half-step; the caller drops the warm start of a later Jacobi fallback)
-    double* Uo = Sm + L::oK;             // [2][ncp][NP]: the tiles of K_0, K_1, V_0, V_1
-    for (int e = tid; e < 2 * ncp * S; e += 256) {
-        const int w = e / (ncp * S), f = e - w * ncp * S, pp = f / S, r = f - pp * S;
-        const double* tw = U + w * ncp * NP + r;
-        // fixed trip count in chunks of 17 terms, the LDS reads of a chunk issued before its arithmetic (terms a >= ncp masked
-        // by a select)
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        constexpr int CHK = 17;
-        static_for<0, (NCM + CHK - 1) / CHK>([&](auto Cc) {
-            constexpr int c0 = Cc * CHK, c1 = (c0 + CHK < NCM) ? c0 + CHK : NCM;
-            double dv[CHK], tv[CHK];
-            static_for<c0, c1>([&](auto Ac) {
-                const int ai = (Ac < ncp) ? (int)Ac : 0;
-                dv[Ac - c0] = Dt[ai * ncp + pp];
-                tv[Ac - c0] = tw[ai * NP];
+    // cardinal vectors u_p = sum_a D[a][p] t_a, into the tiles of K_0, K_1, V_0, V_1 (the matrices have done their work for
+    // this half-step; the caller drops the warm start of a later Jacobi fallback), then the weights W[p][q] = u_p(K_0) . u_q(K_1).
+    // Both are small matrix products -- [ncp x ncp]^T [ncp x S] per matrix, [ncp x S] [S x ncp] -- on the fp64 matrix core, one
+    // 16 x 16 tile per wave and pass (as one thread per entry with a masked loop over kNcpMax terms: 6 k + 2.5 k cycles per
+    // step).  Operands outside the true extents: addresses clamped, one side zeroed.
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
+    double* Uo = Sm + L::oK;             // [2][ncp][NP]
+    const int sp = (ncp + 15) >> 4;      // row tiles of p
+    {
+        constexpr int SC = (S + 15) / 16, KA = (NCM + 3) / 4;
+        for (int tile = wv; tile < 2 * sp * SC; tile += 4) {
+            const int w = tile / (sp * SC), rem = tile - w * sp * SC, ti = rem / SC, tj = rem - ti * SC;
+            const int pp = 16 * ti + r16, r = 16 * tj + r16;
+            const double* da = Dt + min(pp, ncp - 1);                       // A[i = p][k = a] = D[a][p]
+            const double* tb = U + w * ncp * NP + min(r, NP - 1);           // B[k = a][j = r] = t_a[r]
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            double av[KA], bv[KA];
+            static_for<0, KA>([&](auto Sc) {
+                const int ai = 4 * Sc + kk, ac = min(ai, ncp - 1);
+                const double x = da[ac * ncp];
+                av[Sc] = (ai < ncp) ? x : 0.0; bv[Sc] = tb[ac * NP];
             });
-            static_for<c0, c1>([&](auto Ac) {
-                const double t = (Ac < ncp) ? tv[Ac - c0] : 0.0;
-                if constexpr (Ac % 3 == 0) a0 = fma(dv[Ac - c0], t, a0);
-                else if constexpr (Ac % 3 == 1) a1 = fma(dv[Ac - c0], t, a1);
-                else a2 = fma(dv[Ac - c0], t, a2);
+            static_for<0, KA>([&](auto Sc) {
+                if (4 * Sc < ncp) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[Sc], bv[Sc], acc, 0, 0, 0);
             });
-        });
-        Uo[(w * ncp + pp) * NP + r] = (a0 + a1) + a2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int po = 16 * ti + kk + 4 * q;
+                if (po < ncp && r < S) Uo[(w * ncp + po) * NP + r] = acc[q];
+            }
+        }
     }
     __syncthreads();
     double* W = Sm + L::oW;
-    const double* U0 = Uo;
-    const double* U1 = Uo + ncp * NP;
-    for (int e = tid; e < ncp * ncp; e += 256) {
-        const int pp = e / ncp, q = e - pp * ncp;
-        const double* u = U0 + pp * NP;
-        const double* v = U1 + q * NP;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        static_for<0, S>([&](auto Jc) {
-            constexpr int j = Jc;
-            if constexpr (j % 3 == 0) a0 = fma(u[j], v[j], a0);
-            else if constexpr (j % 3 == 1) a1 = fma(u[j], v[j], a1);
-            else a2 = fma(u[j], v[j], a2);
-        });
-        W[e] = (a0 + a1) + a2;
+    {
+        constexpr int KS = (S + 3) / 4;
+        for (int tile = wv; tile < sp * sp; tile += 4) {
+            const int ti = tile / sp, tj = tile - ti * sp;
+            const double* ua = Uo + min(16 * ti + r16, ncp - 1) * NP;
+            const double* ub = Uo + ncp * NP + min(16 * tj + r16, ncp - 1) * NP;
+            double av[KS], bv[KS];
+            static_for<0, KS>([&](auto Sc) {
+                constexpr int j0 = 4 * Sc;
+                if constexpr (j0 + 3 < S) { av[Sc] = ua[j0 + kk]; bv[Sc] = ub[j0 + kk]; }
+                else {
+                    const int jc = min(j0 + kk, S - 1);
+                    const double x = ua[jc];
+                    av[Sc] = (j0 + kk < S) ? x : 0.0; bv[Sc] = ub[jc];
+                }
+            });
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            static_for<0, KS>([&](auto Sc) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[Sc], bv[Sc], acc, 0, 0, 0); });
+            const int q = 16 * tj + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pp = 16 * ti + kk + 4 * r;
+                if (pp < ncp && q < ncp) W[pp * ncp + q] = acc[r];
+            }
+        }
     }
     __syncthreads();
 }
@@ -1608,6 +1649,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
     for (int t = a.t_begin; t < a.t_end; ++t) {
         if (!dead) {
             bool bad = false;
+
             // The two half-steps share ONE call site of the front end (inlined there: as a called function it saved and
             // restored two dozen callee-saved registers through scratch on every call, and twice inlined it doubles the
             // largest piece of straight-line code in the kernel).
@@ -1793,17 +1835,19 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double* W = Sm + L::oW;
                     const double qm0 = mean0, qm1 = mean1, qs0 = scale0, qs1 = scale1;
                     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                    for (int e = tid; e < Rn; e += 256) {
-                        const int i0 = e / Sn, i1 = e - i0 * Sn;
-                        const double w = W[e];
-                        const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[LS + i1], qs1, qm1);
-                        s0 = fma(w, poly2d(coef + 0 * DD, a.D, a.ext[0], x0, x1), s0);       // mu_0(x)
-                        s1 = fma(w, poly2d(coef + 1 * DD, a.D, a.ext[1], x0, x1), s1);       // mu_1(x)
-                        if (scaled) {  // scale <- sqrt(sum w var_k(x)), filtering.py:186
-                            s2 = fma(w, poly2d(coef + 2 * DD, a.D, a.ext[2], x0, x1), s2);
-                            s3 = fma(w, poly2d(coef + 4 * DD, a.D, a.ext[4], x0, x1), s3);
+                    dispatch_extent<L::kMaxD>(a.D, [&](auto Dc) {
+                        for (int e = tid; e < Rn; e += 256) {
+                            const int i0 = e / Sn, i1 = e - i0 * Sn;
+                            const double w = W[e];
+                            const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[LS + i1], qs1, qm1);
+                            s0 = fma(w, poly2d_full<Dc>(coef + 0 * DD, x0, x1), s0);       // mu_0(x)
+                            s1 = fma(w, poly2d_full<Dc>(coef + 1 * DD, x0, x1), s1);       // mu_1(x)
+                            if (scaled) {  // scale <- sqrt(sum w var_k(x)), filtering.py:186
+                                s2 = fma(w, poly2d_full<Dc>(coef + 2 * DD, x0, x1), s2);
+                                s3 = fma(w, poly2d_full<Dc>(coef + 4 * DD, x0, x1), s3);
+                            }
                         }
-                    }
+                    });
                     s0 = wave_sum64(s0); s1 = wave_sum64(s1);
                     if (scaled) { s2 = wave_sum64(s2); s3 = wave_sum64(s3); }
                     if ((tid & 63) == 0) {
@@ -1827,6 +1871,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     //   M(0,b) = m_1 M(0,b-1) + (b-1) S_11 M(0,b-2)
                     //   M(a,b) = m_0 M(a-1,b) + (a-1) S_00 M(a-2,b) + b S_01 M(a-1,b-1)
                     // three rows of the table live at a time; entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b
+                    dispatch_extent<L::kMaxD>(a.D, [&](auto Dc) {
                     for (int base = 0; base < Rn; base += 256) {
                         double wA, mA0, mA1, sA00, sA01, sA11;
                         {
@@ -1835,11 +1880,11 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                             const int iA0 = okA ? eA / Sn : 0, iA1 = okA ? eA - iA0 * Sn : 0;
                             wA = okA ? W[eA] : 0.0;
                             const double xA0 = fma(lam[iA0], qs0, qm0), xA1 = fma(lam[LS + iA1], qs1, qm1);
-                            mA0 = poly2d(coef + 0 * DD, a.D, a.ext[0], xA0, xA1) - c0;
-                            mA1 = poly2d(coef + 1 * DD, a.D, a.ext[1], xA0, xA1) - c1;
-                            sA00 = poly2d(coef + 2 * DD, a.D, a.ext[2], xA0, xA1);
-                            sA01 = poly2d(coef + 3 * DD, a.D, a.ext[3], xA0, xA1);
-                            sA11 = poly2d(coef + 4 * DD, a.D, a.ext[4], xA0, xA1);
+                            mA0 = poly2d_full<Dc>(coef + 0 * DD, xA0, xA1) - c0;
+                            mA1 = poly2d_full<Dc>(coef + 1 * DD, xA0, xA1) - c1;
+                            sA00 = poly2d_full<Dc>(coef + 2 * DD, xA0, xA1);
+                            sA01 = poly2d_full<Dc>(coef + 3 * DD, xA0, xA1);
+                            sA11 = poly2d_full<Dc>(coef + 4 * DD, xA0, xA1);
                         }
                         double MA[3][P], bt[16];
                         static_for<0, P>([&](auto N0c) {
@@ -1870,6 +1915,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                             });
                         });
                     }
+                    });
                     __syncthreads();
                     if (tid < Z) {
                         int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
@@ -1907,6 +1953,10 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 // some factor have not converged.
                 ND_STAMP_BEGIN;
                 if (tid == 0) Sm[L::oMisc + 6] = 0.0;
+                // this step's measurements (loaded at the top of the step -- 1.5 k cycles earlier -- they cost four registers
+                // across the prediction and the front end, and the pass got 3 % slower)
+                double ypre[MFS_ND_MAX_FACTORS];
+                static_for<0, MFS_ND_MAX_FACTORS>([&](auto Qc) { ypre[Qc] = (Qc < a.n_factors) ? yrow[(size_t)t * a.ny + a.fac_ycol[Qc]] : 0.0; });
                 __syncthreads();
                 double c0 = 0.0, c1 = 0.0;
                 bool done_joint = false;
@@ -1938,7 +1988,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     constexpr int LS = L::LS;
                     const double* lam = Sm + L::oLam;
                     const double* W = Sm + L::oW;
-                    const double yv = yrow[(size_t)t * a.ny + a.fac_ycol[0]];
+                    const double yv = ypre[0];
                     const int lane16 = tid & 15;
                     const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
                     double* myred = red + (tid >> 4) * RW + cls;
@@ -1988,7 +2038,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                   }
                 }
                 if (!done_joint) {
-                cheb_h_nd<N, TK>(Sm, a, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, yrow + (size_t)t * a.ny, mean0, mean1, scale0, scale1);
+                cheb_h_nd<N, TK>(Sm, a, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, ypre, mean0, mean1, scale0, scale1);
                 __syncthreads();
                 if (MFS_ND_FORCE_JACOBI || a.force_eigen || Sm[L::oMisc + 6] != 0.0) {
                     jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
@@ -2002,9 +2052,9 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         if ((lik_mask >> k) & 1) {
                             const double x = fma(Sm[L::oK + k * NP * LD + i * (LD + 1)], k ? scale1 : scale0, k ? mean1 : mean0);
                             double l = 1.0;
-                            for (int f = 0; f < a.n_factors; ++f)
-                                if (a.fac_comp[f] == k)
-                                    l *= likelihood_nd(a.fac_kind[f], Sm + L::oLik + 4 * f, yrow[t * a.ny + a.fac_ycol[f]], x);
+                            static_for<0, MFS_ND_MAX_FACTORS>([&](auto Fc) {
+                                if (Fc < a.n_factors && a.fac_comp[Fc] == k) l *= likelihood_nd(a.fac_kind[Fc], Sm + L::oLik + 4 * Fc, ypre[Fc], x);
+                            });
                             g[k * NP + i] = l * Sm[L::oV + k * NP * LD + i];
                         }
                     }
