@@ -298,6 +298,21 @@ __device__ __forceinline__ double rsq_nr(const double v) {
 // SIMD): ~22 / 33 / 34 VALU instructions for exp / tanh / log against 34 / 155 / 90 for the ocml routines.  Absolute
 // accuracy ~1-2 ulp of the result's magnitude scale; tanh keeps ABSOLUTE (not relative) accuracy near zero, which is
 // what a polynomial in tanh x needs.
+// (SC: the polynomial's constants as SCALAR operands of `v_fma_f64`.  The plain form compiles to `v_fmac_f64`, whose
+//  addend is the destination, so every constant is first copied into a vector register pair -- loop-invariant copies that
+//  get hoisted out of the time loop.  The 1-D kernels have the registers for that; the N-D kernel does not, spilled them and
+//  reloaded each one from scratch between two dependent multiply-adds: ten serialised `s_waitcnt vmcnt(0)` per exponential.)
+template <bool SC>
+__device__ __forceinline__ double fma_const(const double p, const double r, const double c) {
+    if constexpr (SC) {
+        double o;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "s"(c));
+        return o;
+    } else {
+        return fma(p, r, c);
+    }
+}
+template <bool SC = false>
 __device__ __forceinline__ double fast_exp(const double y) {
     // e^y = 2^k e^r, k = rint(y / ln 2), |r| <= ln 2 / 2, Taylor to degree 13 (r^14 / 14! < 5e-18)
     const double yc = vmin_f64(vmax_f64(y, -745.5), 710.0);     // e^710 = +inf as in libm (the clamp would swallow a NaN: restored below)
@@ -305,16 +320,16 @@ __device__ __forceinline__ double fast_exp(const double y) {
     double r = fma(k, -0.6931471803691238, yc);                  // ln 2 split: hi part has 21 trailing zero bits
     r = fma(k, -1.9082149292705877e-10, r);
     double p = 1.6059043836821613e-10;                           // 1 / 13!
-    p = fma(p, r, 2.08767569878681e-09);
-    p = fma(p, r, 2.505210838544172e-08);
-    p = fma(p, r, 2.755731922398589e-07);
-    p = fma(p, r, 2.7557319223985893e-06);
-    p = fma(p, r, 2.48015873015873e-05);
-    p = fma(p, r, 0.0001984126984126984);
-    p = fma(p, r, 0.001388888888888889);
-    p = fma(p, r, 0.008333333333333333);
-    p = fma(p, r, 0.041666666666666664);
-    p = fma(p, r, 0.16666666666666666);
+    p = fma_const<SC>(p, r, 2.08767569878681e-09);
+    p = fma_const<SC>(p, r, 2.505210838544172e-08);
+    p = fma_const<SC>(p, r, 2.755731922398589e-07);
+    p = fma_const<SC>(p, r, 2.7557319223985893e-06);
+    p = fma_const<SC>(p, r, 2.48015873015873e-05);
+    p = fma_const<SC>(p, r, 0.0001984126984126984);
+    p = fma_const<SC>(p, r, 0.001388888888888889);
+    p = fma_const<SC>(p, r, 0.008333333333333333);
+    p = fma_const<SC>(p, r, 0.041666666666666664);
+    p = fma_const<SC>(p, r, 0.16666666666666666);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -331,13 +346,14 @@ __device__ __forceinline__ double fast_tanh(const double x) {
 
 // natural logarithm of a positive finite number (anything else gives a non-finite result, which is all the caller needs:
 // a non-finite negative log-likelihood poisons the replicate)
+template <bool SC = false>
 __device__ __forceinline__ double fast_log(const double v) {
     // v = m 2^e, m in [0.5, 1): ln m from the fp32 hardware log as a seed y0 and one exact correction
     // ln m = y0 + log1p(m e^{-y0} - 1), |m e^{-y0} - 1| ~ 1e-7
     const double m = __builtin_amdgcn_frexp_mant(v);
     const int ex = __builtin_amdgcn_frexp_exp(v);
     const double y0 = (double)(__builtin_amdgcn_logf((float)m) * 0.6931471805599453f);
-    const double d = fma(m, fast_exp(-y0), -1.0);
+    const double d = fma(m, fast_exp<SC>(-y0), -1.0);
     const double lnm = y0 + fma(-0.5 * d, d, d);
     const double r = fma((double)ex, 0.6931471805599453, lnm);
     const double inf = __builtin_inf();

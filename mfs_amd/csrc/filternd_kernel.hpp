@@ -365,16 +365,21 @@ __device__ __forceinline__ void dispatch_extent(const int D, F&& f) {
     static_for<1, DMAX + 1>([&](auto Dc) { if (D == Dc) f(Dc); });
 }
 
-// the Bernoulli-logistic likelihood (mfs/multi_dims/ss_models.py:63-67) with the in-line exponential; other kinds through
-// the generic routine
+// the likelihood kinds of include/mfs_hip.h with the in-line exponential / logarithm in their scalar-constant form
+// (fast_exp<true>: see there); Bernoulli-logistic is mfs/multi_dims/ss_models.py:63-67
 __device__ __forceinline__ double likelihood_nd(const int kind, const double* __restrict__ lp, const double y,
                                                 const double x) {
     if (kind == MFS_LIK_BERNOULLI_LOGISTIC) {
         const double z = lp[0] + x * (lp[1] + x * (lp[2] + x * lp[3]));
-        const double p = rcp_sat(1.0 + fast_exp(-z));
+        const double p = rcp_sat(1.0 + fast_exp<true>(-z));
         return (y > 0.5) ? p : 1.0 - p;
     }
-    return likelihood(kind, lp, y, x);
+    if (kind == MFS_LIK_POISSON_SOFTPLUS) {
+        const double rate = fast_log<true>(1.0 + fast_exp<true>(lp[0] * x));
+        return fast_exp<true>(y * fast_log<true>(rate) - rate - log_factorial(y));
+    }
+    const double r = y - fma(lp[0], x, lp[1]);
+    return fast_exp<true>(-0.5 * r * r * rcp_nr(lp[2])) * rsq_nr(6.283185307179586476925 * lp[2]);
 }
 
 // a factor of BOTH state components (fac_component = 2).  MFS_LIK_BEARING_GAUSSIAN: y ~ N(atan2(x_1, x_0), lp[0]) -- the
@@ -383,7 +388,7 @@ __device__ __forceinline__ double likelihood_joint_nd(const int kind, const doub
                                                       const double x0, const double x1) {
     if (kind == MFS_LIK_BEARING_GAUSSIAN) {
         const double r = y - atan2(x1, x0);
-        return fast_exp(-0.5 * r * r * rcp_nr(lp[0])) * rsq_nr(6.283185307179586476925 * lp[0]);
+        return fast_exp<true>(-0.5 * r * r * rcp_nr(lp[0])) * rsq_nr(6.283185307179586476925 * lp[0]);
     }
     return __builtin_nan("");
 }
@@ -2032,7 +2037,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double py = M[0];
                     const double ipy = 1.0 / py;
                     if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
-                    nell -= fast_log(py);
+                    nell -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
                     shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                   }
@@ -2094,7 +2099,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double py = M[0];
                     const double ipy = 1.0 / py;
                     if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
-                    nell -= fast_log(py);
+                    nell -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
                     shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                 } else {
@@ -2110,7 +2115,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double ipy = 1.0 / py;
                     const double dl0 = raw ? 0.0 : a10 * ipy, dl1 = raw ? 0.0 : a01 * ipy;      // posterior mean - mean, in units of lambda
                     if (!raw) { c0 = fma(scale0, dl0, mean0); c1 = fma(scale1, dl1, mean1); }
-                    nell -= fast_log(py);
+                    nell -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read PK[.][1] before the powers overwrite it)
                     krylov_nd<N, TK>(Sm, P, 3, dl0, dl1);
                     __syncthreads();
