@@ -24,6 +24,7 @@
 // loops (a few to a few thousand filters per launch), not the throughput benchmark.
 #pragma once
 #include "filter1d_kernel.hpp"
+#include "filter1d_fast.hpp"     // static_for
 
 namespace mfs {
 
@@ -431,10 +432,16 @@ __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGrad
                 }
             } else {
                 // E[(X' - c)^n | x] = sum_k Q_k(u) n!/(n-k)! (x - c)^(n-k), Q_0 = 1
+                // (every index into Q and D below is a compile-time constant: with the run-time bound `k <= a.n_terms` on a loop
+                //  over them the two arrays lived in scratch memory -- 144 (1 + P) bytes per lane, a load and a `s_waitcnt vmcnt(0)`
+                //  per access)
                 Dual<P> Q[MFS_MAX_TERMS + 1];
                 Q[0] = dconst<P>(1.0);
-                for (int k = 1; k <= MFS_MAX_TERMS; ++k)
-                    Q[k] = (k <= a.n_terms) ? dhorner<P>(coef + (k - 1) * J1, dcoef + (k - 1) * J1, ncoef, a.degree, u) : dconst<P>(0.0);
+                static_for<1, MFS_MAX_TERMS + 1>([&](auto Kc) {
+                    constexpr int k = Kc;
+                    if (k <= a.n_terms) Q[k] = dhorner<P>(coef + (k - 1) * J1, dcoef + (k - 1) * J1, ncoef, a.degree, u);
+                    else Q[k] = dconst<P>(0.0);
+                });
                 if (a.mode != MFS_MODE_RAW) { mean = dgroup_sum<P, G>(w * (x + Q[1])); c = mean; }
                 if (a.mode == MFS_MODE_SCALED) {
                     const Dual<P> var = dhorner<P>(coef + a.n_terms * J1, dcoef + a.n_terms * J1, ncoef, a.degree, u);
@@ -444,14 +451,20 @@ __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGrad
                 const Dual<P> dx = x - c;
                 Dual<P> D[MFS_MAX_TERMS + 1];
                 D[0] = dconst<P>(1.0);
-                for (int k = 1; k <= MFS_MAX_TERMS; ++k) D[k] = dconst<P>(0.0);
+                static_for<1, MFS_MAX_TERMS + 1>([&](auto Kc) { D[Kc] = dconst<P>(0.0); });
                 Dual<P> scn = w;
                 for (int n = 0; n < M2; ++n) {
                     Dual<P> val = dconst<P>(0.0);
-                    for (int k = a.n_terms; k >= 0; --k) val = val + Q[k] * D[k];
+                    static_for<0, MFS_MAX_TERMS + 1>([&](auto Kc) {
+                        constexpr int k = MFS_MAX_TERMS - Kc;       // from k = n_terms down to 0, as the plain filter sums them
+                        if (k <= a.n_terms) val = val + Q[k] * D[k];
+                    });
                     store_contrib(n, scn * val);
                     scn = scn * inv_sc;
-                    for (int k = MFS_MAX_TERMS; k >= 1; --k) D[k] = dx * D[k] + (double)k * D[k - 1];
+                    static_for<0, MFS_MAX_TERMS>([&](auto Kc) {
+                        constexpr int k = MFS_MAX_TERMS - Kc;
+                        if (k <= a.n_terms) D[k] = dx * D[k] + (double)k * D[k - 1];
+                    });
                     D[0] = D[0] * dx;
                 }
             }
