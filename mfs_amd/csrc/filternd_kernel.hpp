@@ -33,8 +33,10 @@
 // Front end of every rule (front_nd): H_k = P_k G+ with G+ the Gram matrix extended by the degree-N monomials, so
 // K_k = R^-1 H_k R^-T = D^-1/2 L^-1 (P_k L+) D^1/2 -- one wave eliminates the rows of G+ in registers (L D L^T, columns of L
 // reaching the other lanes as DPP operands after a lane-swap duplication), then solves for the block-tridiagonal band of
-// K_k only (two short unit-triangular substitutions per column).  No H gathers, no index tables.  No MFMA: s <= 28, fp64,
-// sequential.
+// K_k only (two short unit-triangular substitutions per column).  No H gathers, no index tables.
+// Matrix core: the three products of GEMM shape in a step -- the Gram product of the two Krylov families (bilinear_moments_nd)
+// and, in a Normal-closure prediction, the cardinal vectors and the grid weights (cheb_grid_rule_nd) -- are 16 x 16 tiles of
+// v_mfma_f64_16x16x4_f64; everything else is matrix-VECTOR work in a sequential chain (DPP multiply-adds, dpp_matvec).
 #pragma once
 #include "filter1d_fast.hpp"
 
