@@ -312,7 +312,12 @@ __device__ __forceinline__ double fma_const(const double p, const double r, cons
         return fma(p, r, c);
     }
 }
-template <bool SC = false>
+// (Default of the 1-D kernels: off.  MFS_EXP_SC=1 frees ~20 vector registers there -- N = 7: 229 -> 207 -- but they have no
+//  spills to cure and the pass times do not move: headline 6.76 against 6.69 ms, config-4 shard 54.3 against 54.6.)
+#ifndef MFS_EXP_SC
+#define MFS_EXP_SC 0
+#endif
+template <bool SC = (MFS_EXP_SC != 0)>
 __device__ __forceinline__ double fast_exp(const double y) {
     // e^y = 2^k e^r, k = rint(y / ln 2), |r| <= ln 2 / 2, Taylor to degree 13 (r^14 / 14! < 5e-18)
     const double yc = vmin_f64(vmax_f64(y, -745.5), 710.0);     // e^710 = +inf as in libm (the clamp would swallow a NaN: restored below)
@@ -346,7 +351,7 @@ __device__ __forceinline__ double fast_tanh(const double x) {
 
 // natural logarithm of a positive finite number (anything else gives a non-finite result, which is all the caller needs:
 // a non-finite negative log-likelihood poisons the replicate)
-template <bool SC = false>
+template <bool SC = (MFS_EXP_SC != 0)>
 __device__ __forceinline__ double fast_log(const double v) {
     // v = m 2^e, m in [0.5, 1): ln m from the fp32 hardware log as a seed y0 and one exact correction
     // ln m = y0 + log1p(m e^{-y0} - 1), |m e^{-y0} - 1| ~ 1e-7

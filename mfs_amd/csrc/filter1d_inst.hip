@@ -86,7 +86,12 @@ template <int N, int G>
 void reg_fast(int gi) {
     g_cf[N][gi] = &launch_cf_fast<N, G>;
     KernelEntry& e = g_table[N][3 + gi];  // gi: 0..2 = G 16 / 32 / 64, 3 = G 8
-    constexpr int occ = (N <= 16) ? 2 : 1;
+    // (A/B switch.  Three waves per SIMD for N <= 8 -- the config-4 shard's kernel -- is a 168-register build that spills 66
+    //  registers: 59-62 ms against 54.6 at two waves, round 3.)
+#ifndef MFS_FAST_OCC_SMALL
+#define MFS_FAST_OCC_SMALL 2
+#endif
+    constexpr int occ = (N <= 8) ? MFS_FAST_OCC_SMALL : (N <= 16) ? 2 : 1;
     g_fast_filter[N][gi] = &launch_filter_fast<N, G, occ>;
     // stable = 1 / odd moment counts: the extended variant, for the default lane count of the order (others: dense path)
     if constexpr (G == ((N + 1 <= 8) ? 8 : (N + 1 <= 16) ? 16 : (N + 1 <= 32) ? 32 : 64)) {
