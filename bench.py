@@ -69,6 +69,8 @@ WORKLOADS = {
     # BASELINE config 5 (d = 2): per-GPU shard of the 512-replicate batch is set with --B (128 on 4 GPUs)
     'prey_predator_N6_T500_B512_central_tme2': ('prey', 6, 500, 512, 'central', 'tme_2'),
     'prey_predator_N6_T500_B512_central_tme_normal2': ('prey', 6, 500, 512, 'central', 'tme_normal_2'),
+    # ... with stable=True (quadratures.py:154 `ldl=True`: the LDL^T completion of mfs/utils.py:495-538 in every rule)
+    'prey_predator_N6_T500_B512_central_tme2_stable': ('prey', 6, 500, 512, 'central', 'tme_2', {'stable': 1}),
     # the order the reference's CPU script runs (dardel/run_prey_predator_mf.sh:29-30: --N=5, tme_2 and tme_normal_2)
     'prey_predator_N5_T500_B512_central_tme2': ('prey', 5, 500, 512, 'central', 'tme_2'),
     'prey_predator_N5_T500_B512_central_tme_normal2': ('prey', 5, 500, 512, 'central', 'tme_normal_2'),
@@ -89,6 +91,11 @@ OTHER_WORKLOADS = [
     ('prey_predator_N6_T500_B512_central_tme2', 0, 'config5_B512'),
     ('prey_predator_N6_T500_B512_central_tme2', 128, 'config5_4gpu_shard_B128'),
     ('prey_predator_N6_T500_B512_central_tme_normal2', 0, 'config5_tme_normal2'),
+    # the N-D kernel's throughput ceiling (two workgroups per CU: four rounds of 512) and the order the reference's CPU script runs
+    ('prey_predator_N6_T500_B512_central_tme2_stable', 0, 'config5_stable'),
+    ('prey_predator_N6_T500_B512_central_tme2', 2048, 'config5_B2048_throughput'),
+    ('prey_predator_N5_T500_B512_central_tme2', 0, 'config5_N5_tme2'),
+    ('prey_predator_N5_T500_B512_central_tme_normal2', 0, 'config5_N5_tme_normal2'),
 ]
 
 
@@ -244,7 +251,9 @@ class WorkloadND:
         from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
             gram_and_hankel_indices_graded_lexico
         self.name = name
-        self.model, self.N, T0, B0, self.mode, self.transition = WORKLOADS[name]
+        self.model, self.N, T0, B0, self.mode, self.transition = WORKLOADS[name][:6]
+        self.flags = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else {}
+        self.stable = int(self.flags.get('stable', 0))
         self.B, self.T = B or B0, T or T0
         self.full_size = (self.B == B0 and self.T == T0)
         N = self.N
@@ -286,7 +295,7 @@ class WorkloadND:
         self._inds32 = np.ascontiguousarray(self.inds, dtype=np.int32)
         self.plan = C.c_void_p()
         _lib.check(L.mfs_plan_nd_create(C.byref(self.plan), C.byref(self.mstruct), _lib.MODE[mode], self.N, T, B, z,
-                                        _lib.ptr(self._mi32), _lib.ptr(self._inds32), 0, self.device))
+                                        _lib.ptr(self._mi32), _lib.ptr(self._inds32), self.stable, self.device))
         geo = [C.c_int() for _ in range(3)]
         _lib.check(L.mfs_plan_nd_geometry(self.plan, *[C.byref(g) for g in geo]))
         self.geometry = {'threads_per_filter': geo[0].value, 'grid': geo[1].value, 'lds_bytes_per_block': geo[2].value,

@@ -805,6 +805,8 @@ extern "C" int mfs_plan_nd_create(mfs_plan_nd** plan, const mfs_model_nd* model,
         a.fac_kind[f] = model->fac_kind[f]; a.fac_comp[f] = model->fac_component[f]; a.fac_ycol[f] = model->fac_ycol[f];
     }
     a.coef_batched = model->coef_batched; a.lik_batched = model->lik_batched;
+    // stable = 1: the completion on the register front end (a.stable = 1); MFS_ND_STABLE=dense keeps the LDS-tile form (2)
+    if (stable) { const char* e = getenv("MFS_ND_STABLE"); a.stable = (e && strcmp(e, "dense") == 0) ? 2 : 1; }
     if (const char* e = getenv("MFS_ND_UPDATE")) {   // A/B switches, like MFS_SOLVER
         a.force_eigen = (strcmp(e, "eigen") == 0);
         a.joint_grid = (strcmp(e, "grid") == 0);

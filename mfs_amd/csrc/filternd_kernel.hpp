@@ -452,8 +452,12 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
 // Leaves the symmetric K_0, K_1 in their LDS tiles; returns the block-uniform poison flag (a pivot that is not > 0).
 // The index tables are the graded-lex ones of multi_indices.py:185-229 (the host checks that `inds` is that table), so
 // the default path computes the gather arithmetically; stable = 1 (LDL^T completion) keeps the dense LDS-tile form.
-template <int N, int TK>
-__device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable) {
+// (COMPLETE: the completion branch as a compile-time switch -- as a run-time flag its selects sat on the elimination's critical
+//  chain and cost the plain filter 2 % per pass.  Only one of the two instantiations runs in a launch.)
+template <int N, int TK, bool COMPLETE>
+__device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable_arg) {
+    constexpr bool kComplete = COMPLETE;
+    const int stable = kComplete ? stable_arg : 0;
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
     const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
@@ -464,7 +468,8 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
 
     ND_STAMP_BEGIN;
     if (tid == 0) flags[0] = 0.0;
-    if (stable) {
+    const bool dense = stable == 2;      // (A/B: the LDS-tile form of the completion, MFS_ND_STABLE=dense)
+    if (dense) {
         // -- gather (quadratures.py:151-152) for the LDL^T completion below; pad rows / columns are zero
         for (int e = tid; e < NP * NP; e += nthr) {
             const int i = e / NP, j = e - i * NP;
@@ -480,7 +485,7 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
 
     ND_STAMP(0);
     // -- Cholesky (quadratures.py:154) or LDL^T completion (mfs/utils.py:495-538)
-    if (!stable) {
+    if (!dense) {
         // Front end on ONE wave, in registers.  Two facts about monomial Gram matrices carry it (the N-D form of what the
         // 1-D kernel does with its Hankel matrix):
         //   * H_k is G "shifted by e_k": H_k[i][j] = m[alpha_i + e_k + alpha_j] = G+[sigma_k(i)][j] with G+ the Gram matrix
@@ -497,6 +502,12 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
         // as column j is final its UNSCALED entries are spread over the four DPP rows by lane swaps while 1 / d_j forms
         // (the two chains run side by side), the lane's own factor u_rj / d_j multiplies them in fused DPP multiply-adds,
         // and 1 / sqrt(d_j) -- needed only for the rows of R+ that go to LDS -- stays off the chain.
+        // stable = 1 (`ldl=True`, quadratures.py:154 -> mfs/utils.py:495-538): the SAME elimination -- `ldl` is this L D L^T --
+        // and the completed factor R = L diag(f), f_j = d_j < 0 ? eps : sqrt(d_j), eps = 1e-8 ||G||_F, only changes the two
+        // diagonal scalings:  K_k = R^-1 H_k R^-T = F^-1 [L^-1 (P_k L+)] (D F^-1),  i.e. row i by 1 / f_i and column j by
+        // d_j / f_j (= sqrt(d_j) where the pivot is positive).  T = L^-1 (P_k L+) stays block tridiagonal: T D is the symmetric
+        // matrix of <x_k pi_j, pi_i> in the L D L^T-orthogonal polynomials, zero by degree counting outside the band whatever
+        // the signs of the pivots (the 1-D kernel's completed rule rests on the same fact).
         constexpr int SP = S + N + 1;                 // rows of G+
         constexpr int LDR = S + 1;
         static_assert(SP <= 64 && S <= 32, "rows of G+ in one wave, columns of L in DPP rows 0 and 1");
@@ -514,6 +525,12 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
                 const int M = mr + mj;
                 v[j] = mom[M * (M + 1) / 2 + ur + uj];
             });
+            double eps = 0.0;
+            if constexpr (kComplete) {       // eps = 1e-8 ||G||_F over the S x S Gram block (the rows of lanes < S)
+                double f0 = 0.0, f1 = 0.0;
+                static_for<0, S>([&](auto Jc) { if constexpr (Jc % 2 == 0) f0 = fma(v[Jc], v[Jc], f0); else f1 = fma(v[Jc], v[Jc], f1); });
+                eps = 1e-8 * sqrt(wave_sum64((tid < S) ? f0 + f1 : 0.0));
+            }
             __builtin_amdgcn_sched_barrier(0);
             bool bad = false;
             constexpr int S0 = (S < 16) ? S : 16;
@@ -524,7 +541,7 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
                 constexpr int j = Jc;
                 const double uj = v[j];
                 const double dj = bcast<64, j>(uj);
-                bad |= !(dj > 0.0);
+                bad |= kComplete ? !(dj == dj) : !(dj > 0.0);      // (completion: a negative pivot is kept; a zero one gives f = 0 and a non-finite K, as upstream)
                 dmine = (r == j) ? uj : dmine;
                 // 1 / d_j: seed + two Newton steps, the second folded into the product (as in the 1-D kernel)
                 const double y0 = __builtin_amdgcn_rcp(dj);
@@ -550,9 +567,11 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
             });
             if (tid == 0 && bad) flags[0] = 1.0;
             if (tid < SP) static_for<0, S>([&](auto Jc) { Lp[r * LDR + Jc] = tl[Jc]; });      // (the spare lanes hold garbage)
-            {   // sqrt(d_r), 1 / sqrt(d_r): one per lane, in parallel
+            {   // column scale d_r / f_r and row scale 1 / f_r (sqrt(d_r), 1 / sqrt(d_r) without a completion): one per lane, in parallel
                 const double rsd = rsq_nr(dmine);
-                if (tid < S) { sdv[tid] = dmine * rsd; sdv[S + tid] = rsd; }
+                double cs = dmine * rsd, rs = rsd;
+                if (kComplete && dmine < 0.0) { rs = 1.0 / eps; cs = dmine * rs; }
+                if (tid < S) { sdv[tid] = cs; sdv[S + tid] = rs; }
             }
             wave_sync();
             ND_STAMP(21);
@@ -1663,7 +1682,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
             const int tid = nd_tid(Sm + L::oMisc);     // (a fresh value per half-step: see nd_tid)
-            const bool poisoned = front_nd<N, TK>(Sm, a.inds, a.stable);
+            const bool poisoned = a.stable ? front_nd<N, TK, true>(Sm, a.inds, a.stable) : front_nd<N, TK, false>(Sm, a.inds, 0);
             bad = bad || poisoned;
             // =========================================================================================================
             // prediction (filtering.py:262-266 / :330-331 / :183-190)
