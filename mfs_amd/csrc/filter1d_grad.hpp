@@ -270,19 +270,28 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
         hi = fmax(hi, alpha[j].v + r);
     }
     const int k = (l < N) ? l : N - 1;
-    auto count_below = [&](const double x) {   // number of eigenvalues < x (Sturm sequence of the LDL^T pivots)
-        int cnt = 0;
-        double q = alpha[0].v - x;
-        cnt += (q < 0.0);
+    // number of eigenvalues < x: sign changes of the Sturm sequence P_j = (alpha_j - x) P_{j-1} - beta_j P_{j-2}, P_0 = 1 -- the
+    // pivots q_j = P_j / P_{j-1} of the LDL^T of T - x I without forming them (the quotient form is one fp64 DIVISION per j and
+    // bisection step: 64 steps x N divisions were 15 k of the 19 k instructions of a filter step at N = 7).  A zero P_{j-1}
+    // counts as positive, which gives the same total as the pivot form's 1e-300 substitute.  Magnitudes: |P_j| <= (spectral
+    // width)^j, N <= 16 -- far inside the fp64 range for the central / scaled moments this kernel is used on; the sequence is
+    // rescaled by 2^-512 should it ever pass 2^512.
+    auto count_below = [&](const double x) {
+        double p0 = 1.0, p1 = alpha[0].v - x;
+        int cnt = (p1 < 0.0);
 #pragma unroll
         for (int j = 1; j < N; ++j) {
-            q = (alpha[j].v - x) - beta[j].v / ((q != 0.0) ? q : 1e-300);
-            cnt += (q < 0.0);
+            double pn = fma(alpha[j].v - x, p1, -beta[j].v * p0);
+            cnt += ((pn < 0.0) != (p1 < 0.0));
+            if constexpr (N > 8) if (j == 8 && fabs(pn) > 1.3407807929942597e154) { pn *= 7.458340731200207e-155; p1 *= 7.458340731200207e-155; }
+            p0 = p1; p1 = pn;
         }
         return cnt;
     };
+    // 44 halvings of the Gershgorin interval isolate root k to 6e-14 of the spectral width; the Newton steps below finish it
+    // (they were already there after 64 halvings, which the fp64 mantissa cannot even resolve)
     double a = lo, b = hi;
-    for (int it = 0; it < 64; ++it) {
+    for (int it = 0; it < 44; ++it) {
         const double mid = 0.5 * (a + b);
         if (count_below(mid) > k) b = mid; else a = mid;
     }
