@@ -525,7 +525,7 @@ int mfs_filter_1d_grad(const mfs_model_1d* model, const double* dcoef, const dou
         a.m0 = d_m0; a.m0_batched = m0_batched; a.mean0 = d_mean0; a.scale0 = d_scale0; a.ys = d_ys;
         a.out_nell = d_nell; a.out_first_nan = d_fn;
         ga.n_par = n_par; ga.dcoef = d_dcoef; ga.dlik = d_dlik; ga.out_grad = d_grad;
-        e = launch(ga, (B + 3) / 4, s);
+        e = launch(ga, B, s);      // (the launcher knows its lanes per filter)
     }
     auto d2h = [&](void* h, const void* d, size_t bytes) {
         if (e == hipSuccess && h && bytes) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s);

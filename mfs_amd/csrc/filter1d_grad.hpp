@@ -507,6 +507,6 @@ __global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGrad
     }
 }
 
-using Filter1dGradLaunch = hipError_t (*)(const Filter1dGradArgs&, int grid, hipStream_t);
+using Filter1dGradLaunch = hipError_t (*)(const Filter1dGradArgs&, int n_filters, hipStream_t);
 
 }  // namespace mfs
