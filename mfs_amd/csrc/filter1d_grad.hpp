@@ -347,8 +347,14 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
 
 // One filter per G-lane group.  LDS per filter: dual moments [1 + P][2N], contribution table [G][1 + P][2N], the quadrature's
 // scratch (two rows of the sigma table, alpha / beta).
+// (A/B switch: two waves per SIMD for N <= 8, P <= 2 is a 256-register build that spills 135 registers at N = 7, P = 2 and
+//  measured slower -- 154 against 139 ms per host call of 16 384 filters, round 3.)
+#ifndef MFS_GRAD_OCC2
+#define MFS_GRAD_OCC2 0
+#endif
+template <int N, int P> constexpr int grad_occ() { return (MFS_GRAD_OCC2 && N <= 8 && P <= 2) ? 2 : 1; }
 template <int N, int G, int P>
-__global__ __launch_bounds__(64, 1) void filter1d_grad_kernel(const Filter1dGradArgs ga) {
+__global__ __launch_bounds__(64, (grad_occ<N, P>())) void filter1d_grad_kernel(const Filter1dGradArgs ga) {
     const Filter1dArgs& a = ga.f;
     constexpr int M2 = 2 * N, FPW = 64 / G, DW = (1 + P) * M2;
     extern __shared__ __attribute__((aligned(16))) double smem[];
