@@ -216,7 +216,8 @@ struct NdTile {
     // (not for Normal closures: their Jacobi is a fallback now -- strided rounds -- and the 10 KB go to the Chebyshev-grid tables)
     // (round 3: off -- Jacobi is a rarely taken fallback on every path now, and the 10 KB of tables cost the third workgroup per CU)
     static constexpr bool kTables = false;
-    static constexpr int oIdxK = oMisc + 8;
+    static constexpr int oState = oMisc + 8;                 // block-uniform state: mean_0, mean_1, scale_0, scale_1, nell (+ 3 spare)
+    static constexpr int oIdxK = oState + 8;
     static constexpr int nIdxK = kTables ? ((NP - 1) * HP * HP * 4 + 7) / 8 : 0;
     // bilinear-form path: Krylov tiles, the moment array of the rule and its shifted copy, re-centred coefficients
     static constexpr int NPW = P + kMaxD;                  // powers 0 .. 2N-1 + (D-1)
@@ -1544,6 +1545,7 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
 #ifndef MFS_ND_OCC
 #define MFS_ND_OCC 2
 #endif
+#define ND_TID nd_tid(Sm + L::oMisc)
 template <int N, int TK> constexpr int nd_occ() { return MFS_ND_OCC; }
 template <int N, int TK>
 __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const FilterNdArgs a) {
@@ -1624,15 +1626,20 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
         for (int e = tid; e < Z; e += 256) mom[e] = src[e];
         if (resume) for (int e = tid; e < 2 * NP * LD; e += 256) Sm[L::oV + e] = cw[Z + 8 + e];
     }
-    // every thread carries an identical copy of the block-uniform state (mean, scale, nell): they are all computed from
-    // the same LDS values, so no broadcast is ever needed
-    double mean0 = 0.0, mean1 = 0.0, nell = 0.0;
-    double scale0 = 1.0, scale1 = 1.0;
-    if (resume) {
-        mean0 = cw[Z]; mean1 = cw[Z + 1]; scale0 = cw[Z + 2]; scale1 = cw[Z + 3]; nell = cw[Z + 4];
-    } else {
-        if (!raw) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); mean0 = m[0]; mean1 = m[1]; }
-        if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); scale0 = m[0]; scale1 = m[1]; }
+    // The block-uniform state (mean, scale, nell) lives in LDS: st[0..4].  Every thread computes the new values identically from
+    // LDS data (no broadcast is needed), thread 0 writes them back at the end of a half-step, and each half-step reads them
+    // AFTER its front end -- as per-thread variables live across the whole time loop they were spilled to scratch around the
+    // register-hungry phases and came back through `s_waitcnt vmcnt(0)` reloads in two dozen places per step.
+    double* st = Sm + L::oState;
+    if (tid == 0) {
+        double m0v = 0.0, m1v = 0.0, s0v = 1.0, s1v = 1.0, nl = 0.0;
+        if (resume) {
+            m0v = cw[Z]; m1v = cw[Z + 1]; s0v = cw[Z + 2]; s1v = cw[Z + 3]; nl = cw[Z + 4];
+        } else {
+            if (!raw) { const double* m = a.mean0 + (a.m0_batched ? 2 * b : 0); m0v = m[0]; m1v = m[1]; }
+            if (scaled) { const double* m = a.scale0 + (a.m0_batched ? 2 * b : 0); s0v = m[0]; s1v = m[1]; }
+        }
+        st[0] = m0v; st[1] = m1v; st[2] = s0v; st[3] = s1v; st[4] = nl;
     }
     double* red = Sm + L::oRed;
     if (tid == 0) { red[16 * ZB] = 0.0; Sm[L::oMisc + 5] = resume ? cw[Z + 5] : __hiloint2double(0, -1); }   // flag slot 1: step of the first non-finite result (an int in the low word)
@@ -1681,9 +1688,10 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
             // largest piece of straight-line code in the kernel).
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
-            const int tid = nd_tid(Sm + L::oMisc);     // (a fresh value per half-step: see nd_tid)
+            // (ND_TID: a fresh thread id at every use -- even one id per half-step was spilled and reloaded from scratch in four dozen places)
             const bool poisoned = a.stable ? front_nd<N, TK, true>(Sm, a.inds, a.stable) : front_nd<N, TK, false>(Sm, a.inds, 0);
             bad = bad || poisoned;
+            const double mean0 = st[0], mean1 = st[1], scale0 = st[2], scale1 = st[3];
             // =========================================================================================================
             // prediction (filtering.py:262-266 / :330-331 / :183-190)
             // =========================================================================================================
@@ -1699,13 +1707,13 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         const int row = (r4 < 2) ? r4 : L::kTerms - 2 + r4;
                         nlow = max(nlow, max(a.ext[row] & 0xff, a.ext[row] >> 8));
                     }
-                    if (tid < 2 * NP) Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
+                    if (ND_TID < 2 * NP) Sm[L::oPK + (ND_TID / NP) * NPW * NP + (ND_TID % NP)] = (ND_TID % NP == 0) ? 1.0 : 0.0;
                     const int maxdeg = P - 1 + 2 * (a.D - 1);     // highest total degree a re-centred block reaches from a moment
                     if (2 * (nlow - 1) <= P - 1) {
                         // ... which the rule reproduces: its moments of total degree <= 2N - 1 about its own centre ARE the
                         // moments it was built from (quadratures.py:120-178; tests/test_multi_dim_quadrature.py:90-98 hold that
                         // to 1e-12), so the corner is read off the moment vector -- no Krylov steps, no dot products
-                        for (int e = tid; e < nlow * nlow; e += 256) {
+                        for (int e = ND_TID; e < nlow * nlow; e += 256) {
                             const int pp = e / nlow, q = e - pp * nlow, dg = pp + q;
                             double v = 0.0;
                             if (dg <= 2 * (nlow - 1)) {
@@ -1732,7 +1740,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     //      LDS reads independent, then a wave sum (the two nested per-thread loops this replaces were
                     //      5 k cycles of dependent LDS round trips per step).
                     {
-                        const int r4 = tid >> 6, lane = tid & 63;
+                        const int r4 = ND_TID >> 6, lane = ND_TID & 63;
                         const int row = (r4 == 0) ? 1 : (r4 == 1) ? 0 : L::kTerms - 2 + r4;   // kappa (1,0) is row 1, (0,1) row 0; the last two rows are the variances
                         double acc = 0.0;
                         if (r4 < 2 || scaled) {
@@ -1765,13 +1773,13 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     //      blocks re-centred there, Q_kappa(c + eta) in powers of eta, one packed term (kappa, alpha, beta) per
                     //      thread and pass
                     __syncthreads();     // (everybody has read bx and the low corner of M)
-                    if (tid < 128) {
+                    if (ND_TID < 128) {
                         krylov_nd<N, TK>(Sm, npow, 3, (c0 - mean0) / scale0, (c1 - mean1) / scale1);
                     } else {
                         const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
                         const int nt = (int)tw[0];
                         const double* bin = Sm + L::oBin;
-                        for (int e = tid - 128; e < nt; e += 128) {
+                        for (int e = ND_TID - 128; e < nt; e += 128) {
                             const unsigned w = tw[1 + e];
                             const int al = (w >> 6) & 7, be = (w >> 9) & 7, ea = (w >> 12) & 7, eb = (w >> 15) & 7, qi = w >> 18;
                             const double* blk = coef + (qi / DD6) * DD;
@@ -1802,10 +1810,10 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         double* part = Sm + L::oM2;      // [2][Z]
                         static_assert(2 * Z <= NPW * MLD && Z <= 128, "partial sums must fit in the M2 tile");
                         const double* ff = Sm + L::oFf;
-                        int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
-                        const int pair = __builtin_amdgcn_readfirstlane(tid >> 7);
+                        int zn0, zn1; nd_exponents(min(ND_TID & 127, Z - 1), zn0, zn1);    // the moment this thread owns (ND_TID & 127 < Z)
+                        const int pair = __builtin_amdgcn_readfirstlane(ND_TID >> 7);
                         static_assert(L::kTerms < 31, "row words live in the lanes of one register");
-                        const unsigned myrow = reinterpret_cast<const unsigned*>(Sm + L::oRowTab)[tid & 31];
+                        const unsigned myrow = reinterpret_cast<const unsigned*>(Sm + L::oRowTab)[ND_TID & 31];
                         const int nrows = __builtin_amdgcn_readlane(myrow, 31);
                         const double* f0 = ff + zn0 * L::FFS;
                         const double* f1 = ff + zn1 * L::FFS;
@@ -1828,12 +1836,12 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                             });
                             v = fma(fa * fb, in, v);
                         }
-                        if ((tid & 127) < Z) part[pair * Z + (tid & 127)] = v;
+                        if ((ND_TID & 127) < Z) part[pair * Z + (ND_TID & 127)] = v;
                         __syncthreads();
-                        if (tid < Z) {
-                            double v = (part[tid] + part[Z + tid]) + M[zn0 * MLD + zn1];
+                        if (ND_TID < Z) {
+                            double v = (part[ND_TID] + part[Z + ND_TID]) + M[zn0 * MLD + zn1];
                             if (scaled) v *= ipow32(1.0 / ns0, zn0) * ipow32(1.0 / ns1, zn1);
-                            mom[tid] = v;
+                            mom[ND_TID] = v;
                             if (!finite(v)) red[16 * ZB] = 1.0;
                         }
                     }
@@ -1862,7 +1870,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double qm0 = mean0, qm1 = mean1, qs0 = scale0, qs1 = scale1;
                     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
                     dispatch_extent<L::kMaxD>(a.D, [&](auto Dc) {
-                        for (int e = tid; e < Rn; e += 256) {
+                        for (int e = ND_TID; e < Rn; e += 256) {
                             const int i0 = e / Sn, i1 = e - i0 * Sn;
                             const double w = W[e];
                             const double x0 = fma(lam[i0], qs0, qm0), x1 = fma(lam[LS + i1], qs1, qm1);
@@ -1876,8 +1884,8 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     });
                     s0 = wave_sum64(s0); s1 = wave_sum64(s1);
                     if (scaled) { s2 = wave_sum64(s2); s3 = wave_sum64(s3); }
-                    if ((tid & 63) == 0) {
-                        double* r3 = red + 4 * RW * (tid >> 6) + 16 * ZB;
+                    if ((ND_TID & 63) == 0) {
+                        double* r3 = red + 4 * RW * (ND_TID >> 6) + 16 * ZB;
                         r3[1] = s0; r3[2] = s1; r3[4] = s2; r3[5] = s3;
                     }
                     __syncthreads();
@@ -1891,9 +1899,9 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     if (!raw) { c0 = s0; c1 = s1; }
                     if (scaled) { ns0 = sqrt(s2); ns1 = sqrt(s3); }
                     ND_STAMP(6);
-                    const int lane16 = tid & 15;
+                    const int lane16 = ND_TID & 15;
                     const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
-                    double* myred = red + (tid >> 4) * RW + cls;
+                    double* myred = red + (ND_TID >> 4) * RW + cls;
                     //   M(0,b) = m_1 M(0,b-1) + (b-1) S_11 M(0,b-2)
                     //   M(a,b) = m_0 M(a-1,b) + (a-1) S_00 M(a-2,b) + b S_01 M(a-1,b-1)
                     // three rows of the table live at a time; entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b
@@ -1901,7 +1909,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     for (int base = 0; base < Rn; base += 256) {
                         double wA, mA0, mA1, sA00, sA01, sA11;
                         {
-                            const int eA = base + tid;
+                            const int eA = base + ND_TID;
                             const bool okA = eA < Rn;
                             const int iA0 = okA ? eA / Sn : 0, iA1 = okA ? eA - iA0 * Sn : 0;
                             wA = okA ? W[eA] : 0.0;
@@ -1943,9 +1951,9 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     }
                     });
                     __syncthreads();
-                    if (tid < Z) {
-                        int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
-                        const int zi = tid, n0 = zn0, n1 = zn1;
+                    if (ND_TID < Z) {
+                        int zn0, zn1; nd_exponents(min(ND_TID & 127, Z - 1), zn0, zn1);    // the moment this thread owns (ND_TID & 127 < Z)
+                        const int zi = ND_TID, n0 = zn0, n1 = zn1;
                         const int e = n0 * P - n0 * (n0 - 1) / 2 + n1;    // predictions of a Normal closure emit row by row
                         double v = 0.0;
 #pragma unroll
@@ -1962,12 +1970,14 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     }
                     ND_STAMP(7);
                 }
-                if (!raw) { mean0 = c0; mean1 = c1; }
-                if (scaled) { scale0 = ns0; scale1 = ns1; }
+                if (ND_TID == 0) {
+                    if (!raw) { st[0] = c0; st[1] = c1; }
+                    if (scaled) { st[2] = ns0; st[3] = ns1; }
+                }
                 __syncthreads();
                 bad = bad || (red[16 * ZB] != 0.0);
                 __syncthreads();
-                if (tid == 0) red[16 * ZB] = 0.0;
+                if (ND_TID == 0) red[16 * ZB] = 0.0;
             }
             // =========================================================================================================
             // update (filtering.py:268-275 / :333-339 / :192-202): bilinear form with h_k = lik_k(X_k) e_0
@@ -1978,7 +1988,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 // Cyclic Jacobi + spectral evaluation (and a binomial shift of the moment array) only if the coefficients of
                 // some factor have not converged.
                 ND_STAMP_BEGIN;
-                if (tid == 0) Sm[L::oMisc + 6] = 0.0;
+                if (ND_TID == 0) Sm[L::oMisc + 6] = 0.0;
                 // this step's measurements (loaded at the top of the step -- 1.5 k cycles earlier -- they cost four registers
                 // across the prediction and the front end, and the pass got 3 % slower)
                 double ypre[MFS_ND_MAX_FACTORS];
@@ -2015,11 +2025,11 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double* lam = Sm + L::oLam;
                     const double* W = Sm + L::oW;
                     const double yv = ypre[0];
-                    const int lane16 = tid & 15;
+                    const int lane16 = ND_TID & 15;
                     const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
-                    double* myred = red + (tid >> 4) * RW + cls;
+                    double* myred = red + (ND_TID >> 4) * RW + cls;
                     for (int base = 0; base < Rn; base += 256) {
-                        const int eA = base + tid;
+                        const int eA = base + ND_TID;
                         const bool okA = eA < Rn;
                         const int iA0 = okA ? eA / Sn : 0, iA1 = okA ? eA - iA0 * Sn : 0;
                         const double xi0 = lam[iA0] * scale0, xi1 = lam[LS + iA1] * scale1;      // node - mean
@@ -2045,8 +2055,8 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         });
                     }
                     __syncthreads();
-                    if (tid < Z) {          // the sums about the OLD mean into the moment array
-                        int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
+                    if (ND_TID < Z) {          // the sums about the OLD mean into the moment array
+                        int zn0, zn1; nd_exponents(min(ND_TID & 127, Z - 1), zn0, zn1);    // the moment this thread owns (ND_TID & 127 < Z)
                         const int n0 = zn0, n1 = zn1;
                         const int e = n0 * P - n0 * (n0 - 1) / 2 + n1;
                         double v = 0.0;
@@ -2058,7 +2068,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double py = M[0];
                     const double ipy = 1.0 / py;
                     if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
-                    nell -= fast_log<true>(py);
+                    if (ND_TID == 0) st[4] -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
                     shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                   }
@@ -2073,8 +2083,8 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     // ---- g_k[i] = lik_k(x_k,i) V_k[0][i], the spectral coefficients of h_k (or h_k = e_0 where no factor reads
                     //      component k); parked in the rotation records, which are free until the next Jacobi
                     double* g = Sm + L::oCs;
-                    if (tid < 2 * S) {
-                        const int k = tid / S, i = tid - k * S;
+                    if (ND_TID < 2 * S) {
+                        const int k = ND_TID / S, i = ND_TID - k * S;
                         if ((lik_mask >> k) & 1) {
                             const double x = fma(Sm[L::oK + k * NP * LD + i * (LD + 1)], k ? scale1 : scale0, k ? mean1 : mean0);
                             double l = 1.0;
@@ -2090,7 +2100,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     //      for the other component it is the Krylov recurrence from e_0 on the intact K_k.
                     double* GL = Sm + L::oM;     // [2][P][NP]: lambda_i^p g_k[i]; M / M2 are free until the moments are formed
                     static_assert(2 * P * NP <= 2 * NPW * MLD, "spectral coefficient table must fit in the M tiles");
-                    for (int e = tid; e < 2 * P * S; e += 256) {
+                    for (int e = ND_TID; e < 2 * P * S; e += 256) {
                         const int k = e / (P * S), f = e - k * P * S, p = f / S, i = f - p * S;
                         if (!((lik_mask >> k) & 1)) continue;
                         const double lam_i = Sm[L::oK + k * NP * LD + i * (LD + 1)];
@@ -2098,10 +2108,10 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         for (int q = 0; q < p; ++q) v *= lam_i;
                         GL[(k * P + p) * NP + i] = v;
                     }
-                    if (tid < 2 * NP && !((lik_mask >> (tid / NP)) & 1))
-                        Sm[L::oPK + (tid / NP) * NPW * NP + (tid % NP)] = (tid % NP == 0) ? 1.0 : 0.0;
+                    if (ND_TID < 2 * NP && !((lik_mask >> (ND_TID / NP)) & 1))
+                        Sm[L::oPK + (ND_TID / NP) * NPW * NP + (ND_TID % NP)] = (ND_TID % NP == 0) ? 1.0 : 0.0;
                     __syncthreads();
-                    for (int e = tid; e < 2 * P * S; e += 256) {
+                    for (int e = ND_TID; e < 2 * P * S; e += 256) {
                         const int k = e / (P * S), f = e - k * P * S, p = f / S, r = f - p * S;
                         if (!((lik_mask >> k) & 1)) continue;
                         const double* Vr = Sm + L::oV + k * NP * LD + r * LD;
@@ -2120,13 +2130,13 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double py = M[0];
                     const double ipy = 1.0 / py;
                     if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
-                    nell -= fast_log<true>(py);
+                    if (ND_TID == 0) st[4] -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
                     shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
                 } else {
                     // p_y = h_0 . h_1 and the first moments (K_0 h_0) . h_1, h_0 . (K_1 h_1): every wave forms them itself (lane
                     // products and three wave sums), so no broadcast is needed
-                    const int lane = tid & 63;
+                    const int lane = ND_TID & 63;
                     const double* p0 = Sm + L::oPK;
                     const double* p1 = Sm + L::oPK + NPW * NP;
                     const bool in = lane < S;
@@ -2136,7 +2146,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const double ipy = 1.0 / py;
                     const double dl0 = raw ? 0.0 : a10 * ipy, dl1 = raw ? 0.0 : a01 * ipy;      // posterior mean - mean, in units of lambda
                     if (!raw) { c0 = fma(scale0, dl0, mean0); c1 = fma(scale1, dl1, mean1); }
-                    nell -= fast_log<true>(py);
+                    if (ND_TID == 0) st[4] -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read PK[.][1] before the powers overwrite it)
                     krylov_nd<N, TK>(Sm, P, 3, dl0, dl1);
                     __syncthreads();
@@ -2147,32 +2157,36 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 }   // (separable likelihood)
                 double ns0 = 1.0, ns1 = 1.0;
                 if (scaled) { ns0 = sqrt(M[2 * MLD]); ns1 = sqrt(M[2]); }   // posterior standard deviations (:195-197)
-                if (tid < Z) {
-                    const int zi = tid;
-                    int zn0, zn1; nd_exponents(min(tid & 127, Z - 1), zn0, zn1);    // the moment this thread owns (tid & 127 < Z)
+                if (ND_TID < Z) {
+                    const int zi = ND_TID;
+                    int zn0, zn1; nd_exponents(min(ND_TID & 127, Z - 1), zn0, zn1);    // the moment this thread owns (ND_TID & 127 < Z)
                     double v = M[zn0 * MLD + zn1];
                     if (scaled) v *= ipow32(1.0 / ns0, zn0) * ipow32(1.0 / ns1, zn1);
                     mom[zi] = v;
                     if (!finite(v)) red[16 * ZB] = 1.0;
                 }
-                if (!raw) { mean0 = c0; mean1 = c1; }
-                if (scaled) { scale0 = ns0; scale1 = ns1; }
+                if (ND_TID == 0) {
+                    if (!raw) { st[0] = c0; st[1] = c1; }
+                    if (scaled) { st[2] = ns0; st[3] = ns1; }
+                }
                 __syncthreads();
                 bad = bad || (red[16 * ZB] != 0.0);
                 __syncthreads();
-                if (tid == 0) red[16 * ZB] = 0.0;
+                if (ND_TID == 0) red[16 * ZB] = 0.0;
                 ND_STAMP(7);
 #ifdef MFS_ND_STAMPS
                 if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[9] += 1;
 #endif
             }
             }   // half
-            bad = bad || !finite(nell) || !finite(mean0) || !finite(mean1) || !finite(scale0) || !finite(scale1);
+            bad = bad || !finite(st[4]) || !finite(st[0]) || !finite(st[1]) || !finite(st[2]) || !finite(st[3]);
             if (bad) { dead = true; if (tid == 0) Sm[L::oMisc + 5] = __hiloint2double(0, t); }
         } else {
             for (int zi = tid; zi < Z; zi += 256) mom[zi] = qnan;
-            mean0 = mean1 = nell = qnan;
-            if (scaled) scale0 = scale1 = qnan;
+            if (tid == 0) {
+                st[0] = st[1] = st[4] = qnan;
+                if (scaled) st[2] = st[3] = qnan;
+            }
         }
         __syncthreads();
         if (a.out_mom) {
@@ -2180,23 +2194,23 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
             for (int zi = tid; zi < Z; zi += 256) dst[zi] = mom[zi];
         }
         if (tid == 0 && a.out_mean) {
-            a.out_mean[((size_t)b * a.T + t) * 2] = mean0;
-            a.out_mean[((size_t)b * a.T + t) * 2 + 1] = mean1;
+            a.out_mean[((size_t)b * a.T + t) * 2] = st[0];
+            a.out_mean[((size_t)b * a.T + t) * 2 + 1] = st[1];
         }
         if (tid == 0 && a.out_scale) {
-            a.out_scale[((size_t)b * a.T + t) * 2] = scale0;
-            a.out_scale[((size_t)b * a.T + t) * 2 + 1] = scale1;
+            a.out_scale[((size_t)b * a.T + t) * 2] = st[2];
+            a.out_scale[((size_t)b * a.T + t) * 2 + 1] = st[3];
         }
     }
     if (a.t_end < a.T && cw) {      // not the last chunk: park the state
         for (int e = tid; e < Z; e += 256) cw[e] = mom[e];
         for (int e = tid; e < 2 * NP * LD; e += 256) cw[Z + 8 + e] = Sm[L::oV + e];
         if (tid == 0) {
-            cw[Z] = mean0; cw[Z + 1] = mean1; cw[Z + 2] = scale0; cw[Z + 3] = scale1; cw[Z + 4] = nell;
+            cw[Z] = st[0]; cw[Z + 1] = st[1]; cw[Z + 2] = st[2]; cw[Z + 3] = st[3]; cw[Z + 4] = st[4];
             cw[Z + 5] = Sm[L::oMisc + 5]; cw[Z + 6] = dead ? 1.0 : 0.0; cw[Z + 7] = (double)warm_mask;
         }
     } else if (tid == 0) {
-        a.out_nell[b] = nell;
+        a.out_nell[b] = st[4];
         if (a.out_first_nan) a.out_first_nan[b] = __double2loint(Sm[L::oMisc + 5]);
     }
 }
