@@ -27,7 +27,7 @@ int g_quad_ext_lds[MFS_MAX_N + 1][4];
 using Cf1dLaunch = hipError_t (*)(const Cf1dArgs&, int grid, int lds, hipStream_t);
 Cf1dLaunch g_cf[MFS_MAX_N + 1][4];
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes, carry_doubles; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi, launch_joint; int S, Z, lds_bytes, carry_doubles; };
 extern NdEntry g_nd_table[8];  // filternd_inst.hip
 hipError_t launch_elementary(int which, int n, const double* d_x, double* d_out, hipStream_t s);
 extern Filter1dGradLaunch g_grad_table[17][5];  // filter1d_grad_inst.hip: [N <= 16][P <= 4]
@@ -841,7 +841,9 @@ static int plan_nd_launch(mfs_plan_nd* p, const double* d_m0, int m0_batched, co
     a.out_nell = d_out_nell; a.out_first_nan = d_out_first_nan;
     a.t_begin = t0; a.t_end = t1; a.carry = carry;
     const mfs::NdEntry& ke = mfs::g_nd_table[p->N];
-    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : p->hi_terms ? ke.launch_hi : ke.launch)(a, p->B, stream);
+    const bool joint = a.n_factors == 1 && a.fac_comp[0] == 2;
+    hipError_t e = (p->trans_kind == MFS_ND_TRANS_GAUSSIAN ? ke.launch_gauss : p->hi_terms ? ke.launch_hi
+                    : joint ? ke.launch_joint : ke.launch)(a, p->B, stream);
     if (e != hipSuccess) return fail(MFS_EHIP, "N-D kernel launch: %s", hipGetErrorString(e));
     return MFS_OK;
 }

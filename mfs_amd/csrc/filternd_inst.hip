@@ -1,12 +1,12 @@
 // filternd_inst.hip -- instantiates the d = 2 N-D kernels for quadrature orders 2..7 and the transition families
-// (TK = 0 operator table with |kappa| <= 4, TK = 2 with |kappa| <= 6, TK = 1 Normal closure), and registers their launchers.
+// (TK = 0 operator table with |kappa| <= 4, TK = 3 the same with the node tables of a joint likelihood, TK = 2 with |kappa| <= 6, TK = 1 Normal closure), and registers their launchers.
 #include "filternd_kernel.hpp"
 #include "launch_util.hpp"
 
 namespace mfs {
 
 using FilterNdLaunch = hipError_t (*)(const FilterNdArgs&, int grid, hipStream_t);
-struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi; int S, Z, lds_bytes, carry_doubles; };
+struct NdEntry { FilterNdLaunch launch, launch_gauss, launch_hi, launch_joint; int S, Z, lds_bytes, carry_doubles; };
 NdEntry g_nd_table[8];
 
 template <int N, int TK>
@@ -19,8 +19,11 @@ hipError_t launch_nd(const FilterNdArgs& a, int grid, hipStream_t s) {
 
 template <int N>
 void reg_nd() {
-    constexpr int d0 = NdTile<N, 0>::kDoubles, d1 = NdTile<N, 1>::kDoubles, d2 = NdTile<N, 2>::kDoubles;
-    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, &launch_nd<N, 2>, NdTile<N, 0>::S, NdTile<N, 0>::Z,
+    constexpr int d03 = (N <= 6 && NdTile<N, 3>::kDoubles > NdTile<N, 0>::kDoubles) ? NdTile<N, 3>::kDoubles : NdTile<N, 0>::kDoubles;
+    constexpr int d0 = d03, d1 = NdTile<N, 1>::kDoubles, d2 = NdTile<N, 2>::kDoubles;
+    FilterNdLaunch joint = nullptr;     // operator tables + the node tables of a joint likelihood (TK = 3), N <= 6
+    if constexpr (N <= 6) joint = &launch_nd<N, 3>;
+    g_nd_table[N] = NdEntry{&launch_nd<N, 0>, &launch_nd<N, 1>, &launch_nd<N, 2>, joint, NdTile<N, 0>::S, NdTile<N, 0>::Z,
                             (d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2)) * 8, NdTile<N, 0>::kCarry};
     static_assert(NdTile<N, 0>::kCarry == NdTile<N, 1>::kCarry && NdTile<N, 0>::kCarry == NdTile<N, 2>::kCarry, "one carry layout");
     if constexpr (N < 7) reg_nd<N + 1>();

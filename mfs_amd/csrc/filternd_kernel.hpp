@@ -191,19 +191,24 @@ struct NdTile {
     // (Normal closures: the Chebyshev-grid rule parks its cardinal vectors [2][NCP][NP] in the tiles of K_0, K_1, V_0, V_1; at small
     //  N those are smaller than that, hence the pad)
     static constexpr int kUoPad = (TK == 1 && 2 * kNcpMax * NP > 4 * NP * LD) ? 2 * kNcpMax * NP - 4 * NP * LD : 0;
-    static constexpr int oCs = oV + 2 * NP * LD + kUoPad;     // [2][HP][3]
+    // (TK = 0 keeps its tile under a third of a CU's LDS: the rotation records of the Jacobi fallback alias the Chebyshev scratch
+    //  of the evaluation that has just been abandoned when it runs, and the eigenvalue lists exist only where a node rule is formed)
+    static constexpr int oCsSeq = oV + 2 * NP * LD + kUoPad;     // [2][HP][3]
+    static constexpr int nCs = (TK == 0) ? 0 : 2 * HP * 3 + 2;
     // Normal closures integrate over s^2 eigen-nodes (weights W, coordinates lam) or -- when the integrand's degree allows --
     // over an NCP x NCP Chebyshev grid with the weights Omega of the same bilinear form (kNcpMax bounds NCP)
     static constexpr int LS = (NP > kNcpMax) ? NP : kNcpMax;           // stride of the two coordinate lists
     static constexpr int nWt = (R > kNcpMax * kNcpMax) ? R : kNcpMax * kNcpMax;
-    static constexpr int oW = oCs + 2 * HP * 3 + 2;  // [S][S] / [NCP][NCP] node weights (Normal closures)
+    static constexpr int oW = oCsSeq + nCs;  // [S][S] / [NCP][NCP] node weights (Normal closures)
     // a likelihood of both state components is integrated over the s^2 eigen-nodes: the kernels that take one hold the
     // node weights [S][S] and the 16-row reduction table too (not the TME-order-3 tables, whose tile has no room left)
-    static constexpr bool kJoint = (TK == 1) || (TK == 0 && N <= 6);     // (N = 7 with operator tables: a second workgroup per CU matters more)
+    // TK = 3: the operator-table kernel WITH those tiles (picked by the plan for a joint likelihood; TK = 0 does without them
+    // and fits three workgroups per CU)
+    static constexpr bool kJoint = (TK == 1) || (TK == 3 && N <= 6);     // (N = 7 with operator tables: a second workgroup per CU matters more)
     static constexpr int oLam = oW + ((TK == 1) ? ((nWt + 1) & ~1) : kJoint ? ((R + 1) & ~1) : 0); // [2][LS]
     static constexpr int ZB = (Z + 15) / 16;         // batches of 16 moments in the transposing reduction
     static constexpr int RW = 16 * ZB + 6;           // reduction row: moments (padded), flag, 5 scalar sums
-    static constexpr int oRed = oLam + 2 * LS;       // [4 waves x 4 DPP rows][RW]
+    static constexpr int oRed = oLam + (kJoint ? 2 * LS : 0);       // [4 waves x 4 DPP rows][RW]
     static constexpr int nRed = kJoint ? 16 * RW : 16 * ZB + 16;   // (TK = 2: Jacobi test scratch + the flag slot at [16 ZB] only)
     static constexpr int kTerms = nd_terms<TK>(), kRows = nd_rows<TK>(), kMaxD = nd_maxd<TK>();
     static constexpr bool kOperator = (TK != 1);     // operator-table prediction (TK = 0, 2) or Normal closure (TK = 1)
@@ -233,8 +238,8 @@ struct NdTile {
     static constexpr int kUPad = (TK == 1 && 2 * kNcpMax * NP > 2 * NPW * NP + 2 * NPW * MLD) ? 2 * kNcpMax * NP - (2 * NPW * NP + 2 * NPW * MLD) : 0;
     static constexpr int oQs = oM2 + NPW * MLD + kUPad;      // [kRows][kMaxD * kMaxD] (operator path)
     static constexpr int oBin = oQs + (kOperator ? kRows * kMaxD * kMaxD : 0);  // [NPW][NPW] binomial coefficients
-    static constexpr int oBx = oBin + NPW * NPW;             // [kMaxD][kMaxD] spare, then 8 scalars
-    static constexpr int oLik = oBx + kMaxD * kMaxD + 8; // [2][4] likelihood factor parameters
+    static constexpr int oBx = oBin + NPW * NPW;             // 8 scalars (sums of the mean / variance rows)
+    static constexpr int oLik = oBx + 8;                     // [2][4] likelihood factor parameters
     static constexpr int oPw = oLik + 8;                     // [2][NPW] powers of the centre shift
     // Chebyshev evaluation of lik(X_k) e_0: nodes cos(pi (j + 1/2) / NCH), the cosine table of the coefficient transform,
     // per-matrix coefficients and scratch ([2] x (coefficients NCH, vector ping-pong 2 NP, 8 scalars))
@@ -248,9 +253,13 @@ struct NdTile {
     static constexpr int oChW = oChC + NCH * NCH;            // [2][NCH + nChV + 8]
     static constexpr int nChW = NCH + nChV + 8;
     // operator terms (kappa, alpha, beta) inside the extents of their blocks, packed once per launch, and n!/(n-k)!
-    static constexpr int kMaxTermWords = kTerms * kMaxD * kMaxD;       // 504 / 972 u32
-    static constexpr int oTerms = oChW + 2 * nChW;           // [1 + kMaxTermWords] u32 (count first)
-    static constexpr int oFf = oTerms + (kOperator ? (kMaxTermWords + 2) / 2 : 0);   // [P][FFS]
+    static constexpr int kMaxTermWords = kTerms * kMaxD * kMaxD;       // 504 / 1323 u16
+    static constexpr int oCs = (TK == 0) ? oChW : oCsSeq;
+    static_assert(2 * nChW >= 2 * HP * 3 + 2 && 2 * nChW >= 2 * NP, "rotation records / spectral coefficients alias the Chebyshev scratch");
+    static constexpr int oTerms = oChW + 2 * nChW;           // [1 + kMaxTermWords] u16 (count first)
+    // term words: al | be << 3 | ea << 6 | eb << 9 | row << 12 -- u16 where the table has at most 16 rows, u32 for TME order 3
+    using TermWord = std::conditional_t<(kTerms > 16), unsigned, unsigned short>;
+    static constexpr int oFf = oTerms + (kOperator ? ((kMaxTermWords + 1) * (int)sizeof(TermWord) + 7) / 8 : 0);   // [P][FFS]
     // gather indices of G, H_0, H_1 as u16 ([3][S][S]), when they fit next to the rest at two workgroups per CU: the
     // per-rule gather then makes no global-memory round trip
     // the non-empty rows of the operator table, one packed word each (the contraction walks them: see there), count in word 31
@@ -1546,7 +1555,14 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
 #define MFS_ND_OCC 2
 #endif
 #define ND_TID nd_tid(Sm + L::oMisc)
-template <int N, int TK> constexpr int nd_occ() { return MFS_ND_OCC; }
+// ... and three where the tile is under a third of the CU's 160 KB (TK = 0, N <= 6): without MachineLICM (Makefile) the
+// 168-register build has ONE spilled register, where it had 234
+#ifndef MFS_ND_OCC3
+#define MFS_ND_OCC3 1
+#endif
+template <int N, int TK> constexpr int nd_occ() {
+    return (MFS_ND_OCC3 && MFS_ND_OCC == 2 && TK == 0 && 3 * NdTile<N, TK>::kDoubles * 8 <= 160 * 1024) ? 3 : MFS_ND_OCC;
+}
 template <int N, int TK>
 __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N, TK>;
@@ -1588,18 +1604,19 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
         if (e < NCH) Sm[L::oChX + e] = cospi(((double)e + 0.5) / NCH);
         else { const int j = (e - NCH) / NCH, i = (e - NCH) % NCH; Sm[L::oChC + j * NCH + i] = cospi((double)i * ((double)j + 0.5) / NCH); }   // [sample j][coefficient i]
     }
-    if constexpr (L::kOperator) {   // term list: word = k0 | k1 << 3 | al << 6 | be << 9 | ea << 12 | eb << 15 | (k * 36 + al * 6 + be) << 18
-        unsigned* tw = reinterpret_cast<unsigned*>(Sm + L::oTerms);
+    if constexpr (L::kOperator) {   // term list, u16 words: al | be << 3 | ea << 6 | eb << 9 | row << 12 (the re-centring pass decodes them;
+                                    // the contraction walks the rows, below); word 0 = the count
+        using TermWord = typename L::TermWord;
+        TermWord* tw = reinterpret_cast<TermWord*>(Sm + L::oTerms);
         if (tid == 0) {
             unsigned n = 0;
             for (int k = 0; k < a.n_terms_used && k < L::kTerms; ++k) {
                 const int ea = a.ext[k] & 0xff, eb = a.ext[k] >> 8;
                 for (int al = 0; al < ea; ++al)
                     for (int be = 0; be < eb; ++be)
-                        tw[1 + n++] = (unsigned)kKap0[k] | ((unsigned)kKap1[k] << 3) | ((unsigned)al << 6) | ((unsigned)be << 9) |
-                                      ((unsigned)ea << 12) | ((unsigned)eb << 15) | ((unsigned)(k * DD6 + al * L::kMaxD + be) << 18);
+                        tw[1 + n++] = (TermWord)((unsigned)al | ((unsigned)be << 3) | ((unsigned)ea << 6) | ((unsigned)eb << 9) | ((unsigned)k << 12));
             }
-            tw[0] = n;
+            tw[0] = (TermWord)n;
             // row words: k0 | k1 << 3 | ea << 6 | eb << 9 | (index of the row's first term) << 12 | (wave pair that takes it) << 22
             unsigned* rw = reinterpret_cast<unsigned*>(Sm + L::oRowTab);
             unsigned nr = 0, first = 0;
@@ -1762,12 +1779,12 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                             }
                         }
                         acc = wave_sum64(acc);
-                        if (lane == 0) bx[DD6 + r4] = acc;
+                        if (lane == 0) bx[r4] = acc;
                     }
                     __syncthreads();
                     // E[X'_k | x] = x_k + Q_{e_k}(x): the mean of the prediction is the rule's own first moment plus the sum
-                    if (!raw) { c0 = mean0 + M[1 * MLD + 0] + bx[DD6 + 0]; c1 = mean1 + M[0 * MLD + 1] + bx[DD6 + 1]; }
-                    if (scaled) { ns0 = sqrt(bx[DD6 + 2]); ns1 = sqrt(bx[DD6 + 3]); }
+                    if (!raw) { c0 = mean0 + M[1 * MLD + 0] + bx[0]; c1 = mean1 + M[0 * MLD + 1] + bx[1]; }
+                    if (scaled) { ns0 = sqrt(bx[2]); ns1 = sqrt(bx[3]); }
                     ND_STAMP(12);
                     // ---- waves 0, 1: Krylov vectors of the matrices shifted to the NEW mean; meanwhile waves 2, 3: the coefficient
                     //      blocks re-centred there, Q_kappa(c + eta) in powers of eta, one packed term (kappa, alpha, beta) per
@@ -1776,13 +1793,13 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     if (ND_TID < 128) {
                         krylov_nd<N, TK>(Sm, npow, 3, (c0 - mean0) / scale0, (c1 - mean1) / scale1);
                     } else {
-                        const unsigned* tw = reinterpret_cast<const unsigned*>(Sm + L::oTerms);
+                        const typename L::TermWord* tw = reinterpret_cast<const typename L::TermWord*>(Sm + L::oTerms);
                         const int nt = (int)tw[0];
                         const double* bin = Sm + L::oBin;
                         for (int e = ND_TID - 128; e < nt; e += 128) {
                             const unsigned w = tw[1 + e];
-                            const int al = (w >> 6) & 7, be = (w >> 9) & 7, ea = (w >> 12) & 7, eb = (w >> 15) & 7, qi = w >> 18;
-                            const double* blk = coef + (qi / DD6) * DD;
+                            const int al = w & 7, be = (w >> 3) & 7, ea = (w >> 6) & 7, eb = (w >> 9) & 7, row = w >> 12;
+                            const double* blk = coef + row * DD;
                             double acc = 0.0, pi = 1.0;
                             for (int i = al; i < ea; ++i) {
                                 double pj = 1.0, rsum = 0.0;
