@@ -193,3 +193,46 @@ def test_gradient_at_the_headline_order_N15_and_exact_parameter_tangents():
     t_a = estimation._tables_and_tangents(model_a, np.array([np.exp(0.3)]), 'central', 1e-3, 'complex-step')
     npt.assert_allclose(t_c[4], np.exp(0.3) * t_a[4], rtol=1e-14, atol=1e-300)
     npt.assert_allclose(t_s[4], t_c[4], rtol=1e-9, atol=1e-14)               # (the stencil route, kept as the fallback)
+
+
+def test_nd_parameter_gradient_by_differences_in_one_launch():
+    """d = 2: the gradient of the NLL with respect to model parameters (what `jax.grad` through `moment_filter_nd_cms` gives
+    upstream, dardel/parameter_estimation/mf.py:37-54 carried to the N-D filter) from ONE launch of 2P + 1 filters with
+    per-replicate tables (`batch_closures`, `coef_batched` / `lik_batched` of the N-D model).  theta = (dispersion scale,
+    logistic offset) of the prey--predator model at N = 3; checked against central differences of the NumPy oracle's NLL."""
+    from mfs_amd.multi_dims import filtering as fnd, moments as mnd, ss_models as snd
+    from mfs_amd.multi_dims.multi_indices import generate_graded_lexico_multi_indices, \
+        gram_and_hankel_indices_graded_lexico
+    from oracle import multi_dims as omd
+    N, T = 3, 40
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    dt, _, _, gs, drift, _, _, _, _ = snd.prey_predator(mi)
+    _, _, ogs, odrift, _, _, _ = omd.prey_predator(mi)
+    ys, _ = synth.prey_predator_batch(1, T, dt, seed=21)
+    theta = np.array([0.12, 0.8])
+
+    def nell_batch(Pm):
+        R = Pm.shape[0]
+        per = [mnd.sde_cond_moments_tme(drift, (lambda s: (lambda x: np.array([[s * x[0], 0.], [0., s * x[1]]], dtype=object)))(s),
+                                        dt, 2) for s in Pm[:, 0]]
+        fns = mnd.batch_closures(per)
+        pmf = lambda y, x: stats.bernoulli_pmf(y, 1. / (1. + sym.exp(-x[0] ** 3 + Pm[:, 1])))     # noqa: E731
+        return fnd.moment_filter_nd_cms((fns[1], 'multi-index'), fns[3], pmf, np.repeat(ys, R, axis=0), (mi, inds), gs.cms,
+                                        gs.mean)[2]
+
+    f0, g = estimation.nell_and_grad(nell_batch, theta, rel_step=1e-5)
+
+    def oracle_nell(th):
+        odisp = lambda x: [[th[0] * x[0], 0], [0, th[0] * x[1]]]                                       # noqa: E731
+        opmf = lambda y, x: om.bernoulli_pmf(y, 1. / (1. + np.exp(-x[0] ** 3 + th[1])))               # noqa: E731
+        _, ocms, omean, _ = tme_sympy.sde_cond_moments_tme_nd(odrift, odisp, 2, dt, 2, mi)
+        return omd.moment_filter_nd_cms((ocms, 'multi-index'), omean, opmf, ys[0], (mi, inds), ogs.cms, ogs.mean)[2]
+
+    npt.assert_allclose(f0, oracle_nell(theta), rtol=1e-9)
+    for i in range(2):
+        h = 1e-4 * max(abs(theta[i]), 1.0)
+        e = np.zeros(2); e[i] = h
+        ref = (oracle_nell(theta + e) - oracle_nell(theta - e)) / (2 * h)
+        npt.assert_allclose(g[i], ref, rtol=2e-5, atol=1e-7)
+    assert np.all(np.abs(g) > 1e-3)
