@@ -2233,3 +2233,5 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
 }
 
 }  // namespace mfs
+
+#undef ND_TID
