@@ -164,9 +164,13 @@ __device__ __forceinline__ Dual<P> dlikelihood(const int kind, const double* __r
 // read back into registers for the eigenvalue search, their tangents stream through the two dual recurrences.  Lane l < N
 // then owns root l.
 //   qs: per-group scratch, [2][1 + P][2N] rows + [2][1 + P][N] coefficients.
+#ifdef MFS_GRAD_WARM_DEBUG
+__device__ unsigned long long g_grad_warm_dbg[4];
+#endif
 template <int N, int G, int P>
 __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /* [1 + P][2N] */, double* __restrict__ qs, const int l,
-                                                const Dual<P>& mean, const Dual<P>& scale, Dual<P>& x_out, Dual<P>& w_out) {
+                                                const Dual<P>& mean, const Dual<P>& scale, Dual<P>& x_out, Dual<P>& w_out,
+                                                double& warm) {
     constexpr int M2 = 2 * N, DW = (1 + P) * M2;
     double* X = qs;                      // row k - 1
     double* Y = qs + DW;                 // row k - 2
@@ -290,10 +294,52 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
     };
     // 44 halvings of the Gershgorin interval isolate root k to 6e-14 of the spectral width; the Newton steps below finish it
     // (they were already there after 64 halvings, which the fp64 mantissa cannot even resolve)
+    // Warm start (MFS_GRAD_WARM_ROOTS): root k of the same rule one time step ago, three Newton steps, and TWO Sturm counts that
+    // prove the point sits within 1e-4 of the spectral width of root k and of no other root; the halvings run only where that
+    // proof fails in some lane of the wave (the first step, a root that moved too far, roots within 1e-4 of each other).
+    // Measured (Benes, P = 3): 95 % of the lane-rules pass, 53 % of the wave-rules skip the halvings.  The three Newton steps
+    // that finish a root are the same either way.
+#ifndef MFS_GRAD_WARM_ROOTS
+#define MFS_GRAD_WARM_ROOTS 1
+#endif
+#ifndef MFS_GRAD_HALVINGS
+#define MFS_GRAD_HALVINGS 32      // 2e-10 of the spectral width: roots closer than that are one root to the rule; three Newton steps finish
+#endif
+#ifndef MFS_GRAD_WARM_NEWTON
+#define MFS_GRAD_WARM_NEWTON 3
+#endif
+#ifndef MFS_GRAD_WARM_DEL
+#define MFS_GRAD_WARM_DEL 1e-4
+#endif
     double a = lo, b = hi;
-    for (int it = 0; it < 44; ++it) {
-        const double mid = 0.5 * (a + b);
-        if (count_below(mid) > k) b = mid; else a = mid;
+    bool bracketed = false;
+    if (MFS_GRAD_WARM_ROOTS && warm == warm) {
+        double x = warm;
+#pragma unroll
+        for (int it = 0; it < MFS_GRAD_WARM_NEWTON; ++it) {
+            double p0 = 1.0, p1 = x - alpha[0].v, d0 = 0.0, d1 = 1.0;
+#pragma unroll
+            for (int j = 1; j < N; ++j) {
+                const double pn = (x - alpha[j].v) * p1 - beta[j].v * p0;
+                const double dn = p1 + (x - alpha[j].v) * d1 - beta[j].v * d0;
+                p0 = p1; p1 = pn; d0 = d1; d1 = dn;
+            }
+            const double step = p1 / d1;
+            if (finite(step)) x -= step;
+        }
+        const double del = MFS_GRAD_WARM_DEL * (hi - lo);
+        if (x - del > lo && x + del < hi && count_below(x - del) == k && count_below(x + del) == k + 1) {
+            a = x - del; b = x + del; bracketed = true;
+        }
+    }
+#ifdef MFS_GRAD_WARM_DEBUG
+    if (l < N) { atomicAdd(&g_grad_warm_dbg[0], 1ull); if (bracketed) atomicAdd(&g_grad_warm_dbg[1], 1ull); if (__builtin_amdgcn_ballot_w64(!bracketed) == 0 && (threadIdx.x & 63) == 0) atomicAdd(&g_grad_warm_dbg[2], 1ull); if ((threadIdx.x & 63) == 0) atomicAdd(&g_grad_warm_dbg[3], 1ull); }
+#endif
+    if (!bracketed) {
+        for (int it = 0; it < MFS_GRAD_HALVINGS; ++it) {
+            const double mid = 0.5 * (a + b);
+            if (count_below(mid) > k) b = mid; else a = mid;
+        }
     }
     double lam = 0.5 * (a + b);
     for (int it = 0; it < 3; ++it) {           // Newton polish on the monic p_N
@@ -307,6 +353,7 @@ __device__ __forceinline__ bool dual_quadrature(const double* __restrict__ mom /
         const double step = p1 / d1;
         if (finite(step) && lam - step > a - (b - a) && lam - step < b + (b - a)) lam -= step;
     }
+    warm = lam;
     // ---- tangent of the root: one dual evaluation of the recurrence at (lam, 0)
     Dual<P> L0 = dconst<P>(lam);
     {
@@ -391,6 +438,7 @@ __global__ __launch_bounds__(64, (grad_occ<N, P>())) void filter1d_grad_kernel(c
     const double* yrow = a.ys + (size_t)b * a.T;
     bool dead = false;
     int first_nan = -1;
+    double warm_predict = __builtin_nan(""), warm_update = __builtin_nan("");     // this lane's root of the two rules one step ago (in the rule's own units)
     double* myrow = TAB + l * DW;
 
     auto store_contrib = [&](const int n, const Dual<P>& c) {
@@ -425,7 +473,7 @@ __global__ __launch_bounds__(64, (grad_occ<N, P>())) void filter1d_grad_kernel(c
         // ---- prediction
         {
             Dual<P> x, w;
-            bad |= dual_quadrature<N, G, P>(mom, qs, l, mean, scale, x, w);
+            bad |= dual_quadrature<N, G, P>(mom, qs, l, mean, scale, x, w, warm_predict);
             const Dual<P> u = (a.umap == MFS_U_TANH) ? dtanh(x) : x;
             Dual<P> c = dconst<P>(0.0), inv_sc = dconst<P>(1.0);
             if (a.trans_kind == MFS_TRANS_GAUSSIAN) {
@@ -488,7 +536,7 @@ __global__ __launch_bounds__(64, (grad_occ<N, P>())) void filter1d_grad_kernel(c
         // ---- update
         {
             Dual<P> x, w;
-            bad |= dual_quadrature<N, G, P>(mom, qs, l, mean, scale, x, w);
+            bad |= dual_quadrature<N, G, P>(mom, qs, l, mean, scale, x, w, warm_update);
             const Dual<P> wl = w * dlikelihood<P>(a.lik_kind, lp, dlp, a.n_lik, y, x);
             const Dual<P> py = dgroup_sum<P, G>(wl);
             Dual<P> c = dconst<P>(0.0), inv_sc = dconst<P>(1.0);

@@ -1,5 +1,6 @@
 // filter1d_grad_inst.hip -- instantiates the forward-mode gradient kernels (N = 2..16 quadrature nodes, P = 1..4
 // parameters; 8 lanes per filter up to N = 8, 16 above) and registers their launchers.
+#include <cstdio>
 #include "filter1d_grad.hpp"
 #include "launch_util.hpp"
 
@@ -27,6 +28,15 @@ hipError_t launch_grad(const Filter1dGradArgs& a, int n_filters, hipStream_t s) 
     if (hipError_t e = ensure_dynamic_lds<&filter1d_grad_kernel<N, G, P>>(); e != hipSuccess) return e;
     const int lds = grad_lds_bytes<N, P>();
     hipLaunchKernelGGL((filter1d_grad_kernel<N, G, P>), dim3((n_filters + FPW - 1) / FPW), dim3(64), lds, s, a);
+#ifdef MFS_GRAD_WARM_DEBUG
+    {
+        (void)hipStreamSynchronize(s);
+        unsigned long long c[4];
+        (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_grad_warm_dbg), sizeof(c));
+        printf("[warm roots] rules x lanes %llu, warm-started %llu (%.3f); wave-level: %llu of %llu rules skipped the halvings\n", c[0], c[1],
+               (double)c[1] / (double)c[0], c[2], c[3]);
+    }
+#endif
     return hipGetLastError();
 }
 
