@@ -1924,6 +1924,9 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     // three rows of the table live at a time; entries are emitted row by row: slot e(a, b) = a P - a(a-1)/2 + b
                     dispatch_extent<L::kMaxD>(a.D, [&](auto Dc) {
                     for (int base = 0; base < Rn; base += 256) {
+                        // (a wave whose 64 nodes of this pass all lie beyond the rule adds zeros: it skips the pass -- at 23 x 23
+                        //  nodes that is three of the twelve wave-passes, issue slots the co-resident workgroup can use)
+                        if (base > 0 && base + (__builtin_amdgcn_readfirstlane(ND_TID) & ~63) >= Rn) continue;
                         double wA, mA0, mA1, sA00, sA01, sA11;
                         {
                             const int eA = base + ND_TID;
@@ -2046,6 +2049,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     const int cls = ((lane16 & 1) << 3) | ((lane16 & 2) << 1) | ((lane16 & 4) >> 1) | ((lane16 & 8) >> 3);
                     double* myred = red + (ND_TID >> 4) * RW + cls;
                     for (int base = 0; base < Rn; base += 256) {
+                        if (base > 0 && base + (__builtin_amdgcn_readfirstlane(ND_TID) & ~63) >= Rn) continue;     // (as in the prediction's node pass)
                         const int eA = base + ND_TID;
                         const bool okA = eA < Rn;
                         const int iA0 = okA ? eA / Sn : 0, iA1 = okA ? eA - iA0 * Sn : 0;
