@@ -1947,7 +1947,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                                 constexpr int n1 = N1c;
                                 double vA;
                                 if constexpr (n0 == 0) {
-                                    if constexpr (n1 == 0) vA = 1.0;
+                                    if constexpr (n1 == 0) vA = wA;       // (the recursion is linear: started from the node's weight it emits the weighted moments, one multiply per entry less)
                                     else {
                                         vA = mA1 * MA[0][n1 > 0 ? n1 - 1 : 0];
                                         if constexpr (n1 >= 2) vA = fma((double)(n1 - 1) * sA11, MA[0][n1 - 2], vA);
@@ -1959,7 +1959,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                                 }
                                 MA[r][n1] = vA;
                                 constexpr int e = n0 * P - n0 * (n0 - 1) / 2 + n1;
-                                bt[e % 16] = wA * vA;
+                                bt[e % 16] = vA;
                                 if constexpr (e % 16 == 15 || e == Z - 1) {
                                     if constexpr (e % 16 != 15) static_for<e % 16 + 1, 16>([&](auto Jc) { bt[Jc] = 0.0; });
                                     const double v = row_reduce16(bt, lane16);
