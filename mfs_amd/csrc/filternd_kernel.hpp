@@ -1567,7 +1567,7 @@ template <int N, int TK>
 __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const FilterNdArgs a) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
-    constexpr int NPW = L::NPW, MLD = L::MLD, DD6 = L::kMaxD * L::kMaxD;
+    constexpr int NPW = L::NPW, MLD = L::MLD;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
     nd_assign_roles(Sm + L::oMisc);
     const int tid = nd_tid(Sm + L::oMisc), b = blockIdx.x;
