@@ -53,30 +53,54 @@ __device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / d
 #define ND_STAMP_BEGIN do {} while (0)
 #endif
 
-// Work is handed out by "thread id"; most phases of a step run on thread ids 0..63 or 0..127 only, i.e. on one or two of a
-// workgroup's four waves, and two workgroups share a CU.  MFS_ND_SIMD_ROLES=1 takes the id from the SIMD a wave sits on
-// rather than from its position in the workgroup -- role = (SIMD id + 2 * wave-slot parity) & 3, checked in the kernel
-// prologue to be a permutation of 0..3 -- so that the busy waves of the two co-resident workgroups never share a SIMD.
-// Measured (round 3): -9..12 % per step when every workgroup runs the SAME replicate (they are then
-// in lock step and the two busy waves issue the same instructions at the same time), 1 % on a real batch, whose
-// workgroups drift apart within a few steps.  Off by default.
+// Work is handed out by "thread id" = 64 x (the role of the wave) + lane; most phases of a step run on roles 0 or 0..1 only, i.e. on
+// one or two of a workgroup's four waves, and two or three workgroups share a CU.  The role of a wave is NOT its position in the
+// workgroup but a permutation of its SIMD id chosen by the wave slot (MFS_ND_SIMD_ROLES, default on): the waves of a workgroup sit on the four
+// SIMDs in no fixed order, all on the same wave slot, and co-resident workgroups on different slots (tools/diag/hwid.hip) -- so the
+// busy waves of co-resident workgroups land on DIFFERENT SIMDs instead of queueing on one.  The kernel prologue checks that the four
+// roles are a permutation of 0..3 and falls back to the position in the workgroup otherwise (nd_assign_roles).  Measured, round 3:
+// config 5 11.87 -> 11.50 ms, tme_normal_2 16.95 -> 16.35 ms on real batches (-9..12 % when every workgroup runs the same
+// replicate in lock step).  An earlier form that re-read the role from LDS at every use gave the gain back (1 %).
 #ifndef MFS_ND_SIMD_ROLES
-#define MFS_ND_SIMD_ROLES 0
+#define MFS_ND_SIMD_ROLES 1
 #endif
 // (The empty volatile asm makes every call a fresh value to the optimiser.  Without it each inlined helper's thread-dependent
 //  LDS addresses are loop invariants of the time loop, get hoisted out of it by the dozen, do not fit in the register budget of
 //  two workgroups per CU and come back as scratch reloads -- a `s_waitcnt vmcnt(0)` in front of every phase -- where
 //  recomputing them is two or three integer instructions.)
-__device__ __forceinline__ int nd_tid(const double* misc) {
-#if MFS_ND_SIMD_ROLES
-    const int role = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(misc)[threadIdx.x >> 6]);
-    int t = role * 64 + (int)(threadIdx.x & 63);
-#else
-    (void)misc;
-    int t = threadIdx.x;
-#endif
+__device__ __forceinline__ int nd_tid(const int role64) {
+    int t = role64 + (int)(threadIdx.x & 63);
     asm volatile("" : "+v"(t));
     return t;
+}
+#ifdef MFS_ND_ROLE_DEBUG
+__device__ unsigned g_nd_role_fallbacks[2];
+#endif
+// Prologue of the kernel: 64 x (the role of this wave), a scalar.  Two barriers; every thread of the workgroup must call it.
+__device__ __forceinline__ int nd_assign_roles(double* misc) {
+    const int w = threadIdx.x >> 6;
+#if MFS_ND_SIMD_ROLES
+    int* roles = reinterpret_cast<int*>(misc);
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    // role of the wave on SIMD i of a workgroup on wave slot s: nibble i of kMap[s].  Slots 0 and 1 (two workgroups per CU): the two
+    // busiest roles of the two workgroups on four different SIMDs.  Slot 2 (a third workgroup): its role 0 beside a role-1 wave,
+    // its role 1 beside the other role-1 wave -- six busy waves on four SIMDs, none of the three role-0 waves beside another.
+    const unsigned slot = hw & 3u, simd = (hw >> 4) & 3u;
+    const unsigned map = (slot == 0u) ? 0x3210u : (slot == 1u) ? 0x1032u : (slot == 2u) ? 0x1302u : 0x0123u;
+    const int cand = (int)((map >> (4u * simd)) & 3u);
+    if ((threadIdx.x & 63) == 0) roles[w] = cand;
+    __syncthreads();
+    const unsigned seen = (1u << roles[0]) | (1u << roles[1]) | (1u << roles[2]) | (1u << roles[3]);
+    __syncthreads();
+#ifdef MFS_ND_ROLE_DEBUG
+    if (threadIdx.x == 0) { atomicAdd(&g_nd_role_fallbacks[0], seen != 15u ? 1u : 0u); atomicAdd(&g_nd_role_fallbacks[1], cand != 0 ? 1u : 0u); }
+#endif
+    return __builtin_amdgcn_readfirstlane((seen == 15u) ? cand : w) * 64;
+#else
+    (void)misc;
+    return __builtin_amdgcn_readfirstlane(w) * 64;
+#endif
 }
 // exponents (n0, n1) of moment zi in graded lexicographic order: zi = sd (sd + 1) / 2 + n0, sd = n0 + n1  (zi < 2^20)
 __device__ __forceinline__ void nd_exponents(const int zi, int& n0, int& n1) {
@@ -84,30 +108,6 @@ __device__ __forceinline__ void nd_exponents(const int zi, int& n0, int& n1) {
     sd += ((sd + 1) * (sd + 2) / 2 <= zi) ? 1 : 0;
     sd -= (sd * (sd + 1) / 2 > zi) ? 1 : 0;
     n0 = zi - sd * (sd + 1) / 2; n1 = sd - n0;
-}
-#ifdef MFS_ND_ROLE_DEBUG
-__device__ unsigned g_nd_role_fallbacks[2];
-#endif
-// Prologue of the kernel: settle the roles (two barriers; every thread of the workgroup must call it).
-__device__ __forceinline__ void nd_assign_roles(double* misc) {
-#if MFS_ND_SIMD_ROLES
-    int* roles = reinterpret_cast<int*>(misc);
-    const int w = threadIdx.x >> 6;
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const int cand = (int)(((hw >> 4) + 2u * (hw & 1u)) & 3u);    // SIMD id, rotated by two on the odd wave slots
-    if ((threadIdx.x & 63) == 0) roles[w] = cand;
-    __syncthreads();
-    const unsigned seen = (1u << roles[0]) | (1u << roles[1]) | (1u << roles[2]) | (1u << roles[3]);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && seen != 15u) roles[w] = w;
-#ifdef MFS_ND_ROLE_DEBUG
-    if (threadIdx.x == 0) { atomicAdd(&g_nd_role_fallbacks[0], seen != 15u ? 1u : 0u); atomicAdd(&g_nd_role_fallbacks[1], roles[0] != 0 ? 1u : 0u); }
-#endif
-    __syncthreads();
-#else
-    (void)misc;
-#endif
 }
 
 struct FilterNdArgs {
@@ -465,12 +465,12 @@ __device__ __forceinline__ void tournament_pair(const int r, const int P, int& p
 // (COMPLETE: the completion branch as a compile-time switch -- as a run-time flag its selects sat on the elimination's critical
 //  chain and cost the plain filter 2 % per pass.  Only one of the two instantiations runs in a launch.)
 template <int N, int TK, bool COMPLETE>
-__device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable_arg) {
+__device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t* __restrict__ inds, const int stable_arg, const int role64) {
     constexpr bool kComplete = COMPLETE;
     const int stable = kComplete ? stable_arg : 0;
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
-    const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
+    const int tid = nd_tid(role64), nthr = blockDim.x;
     double* mom = Sm + L::oMom;
     double* A = Sm + L::oA;
     double* K = Sm + L::oK;
@@ -749,10 +749,10 @@ __device__ __forceinline__ bool front_nd(double* __restrict__ Sm, const int32_t*
 // prediction, only the components a likelihood factor reads for an update.  warm_mask: bit m set = V_m holds the
 // eigenvectors of an earlier rule of this filter.  On return the diagonal of K_m holds the eigenvalues, V_m the vectors.
 template <int N, int TK>
-__device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int mend, const int warm_mask) {
+__device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int mend, const int warm_mask, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, HP = L::HP, LD = L::LD;
-    const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
+    const int tid = nd_tid(role64), nthr = blockDim.x;
     double* A = Sm + L::oA;
     double* K = Sm + L::oK;
     double* V = Sm + L::oV;
@@ -842,7 +842,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
         dia = Sm[L::oRed + 1] + Sm[L::oRed + 4] + Sm[L::oRed + 7] + Sm[L::oRed + 10];
         xsq = Sm[L::oRed + 2] + Sm[L::oRed + 5] + Sm[L::oRed + 8] + Sm[L::oRed + 11];
 #ifdef MFS_ND_STAMPS
-        if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) {
+        if (blockIdx.x == 0 && nd_tid(role64) == 0) {
             int bin = (off > 0.0 && dia > 0.0) ? (int)(-log10(off / dia)) : 39;
             bin = bin < 0 ? 0 : bin > 39 ? 39 : bin;
             g_nd_hist[sweep < 8 ? sweep : 7][bin] += 1;
@@ -972,7 +972,7 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
         prev_off = off;
         }
 #ifdef MFS_ND_STAMPS
-        if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[8] += 1;
+        if (blockIdx.x == 0 && nd_tid(role64) == 0) g_nd_stamps[8] += 1;
 #endif
 
         for (int r = 0; r < NP - 1; ++r) {
@@ -1097,10 +1097,10 @@ __device__ void jacobi_nd(double* __restrict__ Sm, const int mbeg, const int men
 
 // Eigenvalues and tensor-product weights of the s^2-node rule (quadratures.py:165-170); Normal-closure predictions only.
 template <int N, int TK>
-__device__ void weights_nd(double* __restrict__ Sm) {
+__device__ void weights_nd(double* __restrict__ Sm, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD;
-    const int tid = nd_tid(Sm + L::oMisc), nthr = blockDim.x;
+    const int tid = nd_tid(role64), nthr = blockDim.x;
     const double* K = Sm + L::oK;
     const double* V = Sm + L::oV;
     ND_STAMP_BEGIN;
@@ -1174,10 +1174,10 @@ __device__ __forceinline__ double dpp_matvec(const double (&kr)[S], const double
 // it in registers; a step is one lane swap and S fused DPP multiply-adds (dpp_matvec).  No block barrier inside (one
 // wave per chain); the caller synchronises before and after.
 template <int N, int TK>
-__device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask, const double d0, const double d1) {
+__device__ void krylov_nd(double* __restrict__ Sm, const int npow, const int wmask, const double d0, const double d1, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW;
-    const int tid = nd_tid(Sm + L::oMisc);
+    const int tid = nd_tid(role64);
     if (tid < 128 && ((wmask >> (tid >> 6)) & 1)) {
         const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
         const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
@@ -1228,13 +1228,13 @@ __device__ __forceinline__ double ipow32(double x, int n) {    // x^n, 0 <= n < 
 //  per call, two calls per step.)
 template <int N, int TK>
 __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, const int maxdeg, const double sc0,
-                                    const double sc1, const double fac) {
+                                    const double sc1, const double fac, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, NPW = L::NPW, MLD = L::MLD, KS = (S + 3) / 4;
     static_assert(NPW <= 32, "at most 2 x 2 tiles of 16 x 16");
     typedef double d4 __attribute__((ext_vector_type(4)));
     double* M = Sm + L::oM;
-    const int tid = nd_tid(Sm + L::oMisc);
+    const int tid = nd_tid(role64);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, r16 = lane & 15, kk = lane >> 4;
     const int side = (npow + 15) >> 4;
     for (int tile = w; tile < side * side; tile += 4) {
@@ -1271,22 +1271,22 @@ __device__ void bilinear_moments_nd(double* __restrict__ Sm, const int npow, con
 // table so that the inner loops are plain multiply-adds.
 template <int N, int TK, int NJ>
 __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const int maxdeg, const double d0,
-                                 const double d1, const double fac) {
+                                 const double d1, const double fac, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int NPW = L::NPW, MLD = L::MLD;
     double* M = Sm + L::oM;
     double* M2 = Sm + L::oM2;
     const double* bin = Sm + L::oBin;
     double* pw = Sm + L::oPw;      // [2][NPW]
-    if (nd_tid(Sm + L::oMisc) < 2) {
-        const double d = nd_tid(Sm + L::oMisc) ? -d1 : -d0;
+    if (nd_tid(role64) < 2) {
+        const double d = nd_tid(role64) ? -d1 : -d0;
         double v = 1.0;
-        for (int k = 0; k < NPW; ++k) { pw[nd_tid(Sm + L::oMisc) * NPW + k] = v; v *= d; }
+        for (int k = 0; k < NPW; ++k) { pw[nd_tid(role64) * NPW + k] = v; v *= d; }
     }
     __syncthreads();
     // Fixed trip count NJ >= nout with every LDS read of an entry issued before any arithmetic (terms j > a are masked by
     // a select on the loaded value, not by a branch): a loop to the true bound a was one dependent LDS round trip per term.
-    for (int e = nd_tid(Sm + L::oMisc); e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q], q <= maxdeg - a
+    for (int e = nd_tid(role64); e < nout * nout; e += blockDim.x) {   // axis 0: M2[a][q], q <= maxdeg - a
         const int a = e / nout, q = e - a * nout;
         if (a + q > maxdeg) continue;
         double c[NJ], v[NJ];
@@ -1304,7 +1304,7 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
         M2[a * MLD + q] = acc0 + acc1;
     }
     __syncthreads();
-    for (int e = nd_tid(Sm + L::oMisc); e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
+    for (int e = nd_tid(role64); e < nout * nout; e += blockDim.x) {   // axis 1: M[a][b]
         const int a = e / nout, b = e - a * nout;
         if (a + b > maxdeg) continue;
         double c[NJ], v[NJ];
@@ -1338,10 +1338,10 @@ __device__ void shift_moments_nd(double* __restrict__ Sm, const int nout, const 
 template <int N, int TK>
 __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const int lik_mask,
                           const double (&yv)[MFS_ND_MAX_FACTORS], const double mean0, const double mean1,
-                               const double scale0, const double scale1) {
+                               const double scale0, const double scale1, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, NPW = L::NPW, NCH = L::NCH;
-    const int tid = nd_tid(Sm + L::oMisc);
+    const int tid = nd_tid(role64);
     if (tid >= 128) return;
     const int w = tid >> 6, lane = tid & 63, li = (lane < S) ? lane : S - 1;
     const double* Kw = Sm + L::oK + w * NP * LD + li * LD;
@@ -1421,7 +1421,7 @@ __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const 
         if (lane < S) pk[lane] = h;
         ND_STAMP(18);
 #ifdef MFS_ND_STAMPS
-        if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[20] += deg;
+        if (blockIdx.x == 0 && nd_tid(role64) == 0) g_nd_stamps[20] += deg;
 #endif
         // ---- K h as well (K u = half Khat u + mid u): with h it gives p_y and the posterior mean, about which the caller
         //      then takes the powers
@@ -1446,10 +1446,10 @@ __device__ void cheb_h_nd(double* __restrict__ Sm, const FilterNdArgs& a, const 
 // eigen-decomposition: l_p(X_k) e_0 = sum_a D[a][p] T_a(Khat_k) e_0 from NCP - 1 matrix-vector products per matrix.
 // Leaves the grid coordinates (in units of lambda) in lam[k][p] and Omega in W[p][q]; waves 0 and 1 work, then all.
 template <int N, int TK>
-__device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
+__device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp, const int role64) {
     using L = NdTile<N, TK>;
     constexpr int S = L::S, NP = L::NP, LD = L::LD, LS = L::LS, NCM = L::kNcpMax;
-    const int tid = nd_tid(Sm + L::oMisc);
+    const int tid = nd_tid(role64);
     double* U = Sm + L::oU;              // [2][ncp][NP]
     const double* Dt = Sm + L::oChD;     // [a][p], row stride ncp
     if (tid < 128) {
@@ -1554,7 +1554,7 @@ __device__ void cheb_grid_rule_nd(double* __restrict__ Sm, const int ncp) {
 #ifndef MFS_ND_OCC
 #define MFS_ND_OCC 2
 #endif
-#define ND_TID nd_tid(Sm + L::oMisc)
+#define ND_TID nd_tid(role64)
 // ... and three where the tile is under a third of the CU's 160 KB (TK = 0, N <= 6): without MachineLICM (Makefile) the
 // 168-register build has ONE spilled register, where it had 234
 #ifndef MFS_ND_OCC3
@@ -1569,8 +1569,8 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
     constexpr int S = L::S, Z = L::Z, P = L::P, NP = L::NP, LD = L::LD, R = L::R, RW = L::RW, ZB = L::ZB;
     constexpr int NPW = L::NPW, MLD = L::MLD;
     extern __shared__ __attribute__((aligned(16))) double Sm[];
-    nd_assign_roles(Sm + L::oMisc);
-    const int tid = nd_tid(Sm + L::oMisc), b = blockIdx.x;
+    const int role64 = nd_assign_roles(Sm + L::oMisc);      // 64 x (the role of this wave): a scalar, handed to every helper
+    const int tid = nd_tid(role64), b = blockIdx.x;
     const bool scaled = a.mode == MFS_MODE_SCALED;
     const bool raw = a.mode == MFS_MODE_RAW;
     double* mom = Sm + L::oMom;
@@ -1706,7 +1706,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
 #pragma nounroll
             for (int half = 0; half < 2; ++half) {
             // (ND_TID: a fresh thread id at every use -- even one id per half-step was spilled and reloaded from scratch in four dozen places)
-            const bool poisoned = a.stable ? front_nd<N, TK, true>(Sm, a.inds, a.stable) : front_nd<N, TK, false>(Sm, a.inds, 0);
+            const bool poisoned = a.stable ? front_nd<N, TK, true>(Sm, a.inds, a.stable, role64) : front_nd<N, TK, false>(Sm, a.inds, 0, role64);
             bad = bad || poisoned;
             const double mean0 = st[0], mean1 = st[1], scale0 = st[2], scale1 = st[3];
             // =========================================================================================================
@@ -1744,10 +1744,10 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         ND_STAMP(10);
                     } else {     // (orders too low for that: a few Krylov steps from e_0)
                         __syncthreads();
-                        krylov_nd<N, TK>(Sm, nlow, 3, 0.0, 0.0);
+                        krylov_nd<N, TK>(Sm, nlow, 3, 0.0, 0.0, role64);
                         __syncthreads();
                         ND_STAMP(10);
-                        bilinear_moments_nd<N, TK>(Sm, nlow, 2 * (nlow - 1), scale0, scale1, 1.0);
+                        bilinear_moments_nd<N, TK>(Sm, nlow, 2 * (nlow - 1), scale0, scale1, 1.0, role64);
                         __syncthreads();
                     }
                     ND_STAMP(11);
@@ -1791,7 +1791,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     //      thread and pass
                     __syncthreads();     // (everybody has read bx and the low corner of M)
                     if (ND_TID < 128) {
-                        krylov_nd<N, TK>(Sm, npow, 3, (c0 - mean0) / scale0, (c1 - mean1) / scale1);
+                        krylov_nd<N, TK>(Sm, npow, 3, (c0 - mean0) / scale0, (c1 - mean1) / scale1, role64);
                     } else {
                         const typename L::TermWord* tw = reinterpret_cast<const typename L::TermWord*>(Sm + L::oTerms);
                         const int nt = (int)tw[0];
@@ -1813,7 +1813,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     __syncthreads();
                     ND_STAMP(13);
                     // ---- the moment array about the new mean
-                    bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1, 1.0);
+                    bilinear_moments_nd<N, TK>(Sm, npow, maxdeg, scale0, scale1, 1.0, role64);
                     __syncthreads();
                     ND_STAMP(14);
                     // ---- contraction: E_n = M[n] + sum_kappa n!/(n-kappa)! sum_{al,be} Q'_kappa[al][be] M[n - kappa + (al, be)].
@@ -1871,13 +1871,13 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     int Rn = R, Sn = S;
                     if (ncp > 0) {
                         ND_STAMP_BEGIN;
-                        cheb_grid_rule_nd<N, TK>(Sm, ncp);
+                        cheb_grid_rule_nd<N, TK>(Sm, ncp, role64);
                         Rn = ncp * ncp; Sn = ncp;
                         warm_mask = 0;        // (the eigenvector tiles were scratch)
                         ND_STAMP(3);
                     } else {
-                        jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
-                        weights_nd<N, TK>(Sm);
+                        jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask, role64);
+                        weights_nd<N, TK>(Sm, role64);
                         warm_mask = poisoned ? 0 : 3;
                     }
                     ND_STAMP_BEGIN;
@@ -2030,15 +2030,15 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     bool on_grid = false;
                     if constexpr (TK == 1) {
                         if (a.joint_grid && ncp > 0) {
-                            cheb_grid_rule_nd<N, TK>(Sm, ncp);
+                            cheb_grid_rule_nd<N, TK>(Sm, ncp, role64);
                             Rn = ncp * ncp; Sn = ncp;
                             warm_mask = 0;
                             on_grid = true;
                         }
                     }
                     if (!on_grid) {
-                        jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask);
-                        weights_nd<N, TK>(Sm);
+                        jacobi_nd<N, TK>(Sm, 0, 2, poisoned ? 0 : warm_mask, role64);
+                        weights_nd<N, TK>(Sm, role64);
                         warm_mask = poisoned ? 0 : 3;
                     }
                     constexpr int LS = L::LS;
@@ -2091,14 +2091,14 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
                     if (ND_TID == 0) st[4] -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
-                    shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
+                    shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy, role64);
                   }
                 }
                 if (!done_joint) {
-                cheb_h_nd<N, TK>(Sm, a, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, ypre, mean0, mean1, scale0, scale1);
+                cheb_h_nd<N, TK>(Sm, a, (MFS_ND_FORCE_JACOBI || a.force_eigen) ? 0 : lik_mask, ypre, mean0, mean1, scale0, scale1, role64);
                 __syncthreads();
                 if (MFS_ND_FORCE_JACOBI || a.force_eigen || Sm[L::oMisc + 6] != 0.0) {
-                    jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask);
+                    jacobi_nd<N, TK>(Sm, ubeg, uend, poisoned ? 0 : warm_mask, role64);
                     warm_mask = poisoned ? 0 : (warm_mask | lik_mask);
                     __syncthreads();
                     // ---- g_k[i] = lik_k(x_k,i) V_k[0][i], the spectral coefficients of h_k (or h_k = e_0 where no factor reads
@@ -2143,17 +2143,17 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                         if constexpr (S & 1) a0 = fma(Vr[S - 1], gl[S - 1], a0);
                         Sm[L::oPK + (k * NPW + p) * NP + r] = a0 + a1;
                     }
-                    krylov_nd<N, TK>(Sm, P, 3 & ~lik_mask, 0.0, 0.0);
+                    krylov_nd<N, TK>(Sm, P, 3 & ~lik_mask, 0.0, 0.0, role64);
                     __syncthreads();
                     ND_STAMP(15);
-                    bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, 1.0);
+                    bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, 1.0, role64);
                     __syncthreads();
                     const double py = M[0];
                     const double ipy = 1.0 / py;
                     if (!raw) { c0 = fma(M[1 * MLD], ipy, mean0); c1 = fma(M[1], ipy, mean1); }
                     if (ND_TID == 0) st[4] -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read M[0], M[1], M[MLD] before the shift overwrites M)
-                    shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy);
+                    shift_moments_nd<N, TK, P>(Sm, P, P - 1, c0 - mean0, c1 - mean1, ipy, role64);
                 } else {
                     // p_y = h_0 . h_1 and the first moments (K_0 h_0) . h_1, h_0 . (K_1 h_1): every wave forms them itself (lane
                     // products and three wave sums), so no broadcast is needed
@@ -2169,10 +2169,10 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                     if (!raw) { c0 = fma(scale0, dl0, mean0); c1 = fma(scale1, dl1, mean1); }
                     if (ND_TID == 0) st[4] -= fast_log<true>(py);
                     __syncthreads();   // (everybody has read PK[.][1] before the powers overwrite it)
-                    krylov_nd<N, TK>(Sm, P, 3, dl0, dl1);
+                    krylov_nd<N, TK>(Sm, P, 3, dl0, dl1, role64);
                     __syncthreads();
                     ND_STAMP(15);
-                    bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, ipy);
+                    bilinear_moments_nd<N, TK>(Sm, P, P - 1, scale0, scale1, ipy, role64);
                     __syncthreads();
                 }
                 }   // (separable likelihood)
@@ -2196,7 +2196,7 @@ __global__ __launch_bounds__(256, (nd_occ<N, TK>())) void filternd_kernel(const 
                 if (ND_TID == 0) red[16 * ZB] = 0.0;
                 ND_STAMP(7);
 #ifdef MFS_ND_STAMPS
-                if (blockIdx.x == 0 && nd_tid(Sm + L::oMisc) == 0) g_nd_stamps[9] += 1;
+                if (blockIdx.x == 0 && nd_tid(role64) == 0) g_nd_stamps[9] += 1;
 #endif
             }
             }   // half
