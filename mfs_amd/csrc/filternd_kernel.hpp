@@ -59,8 +59,8 @@ __device__ unsigned long long g_nd_hist[8][40];   // [test index][-log10(off / d
 // SIMDs in no fixed order, all on the same wave slot, and co-resident workgroups on different slots (tools/diag/hwid.hip) -- so the
 // busy waves of co-resident workgroups land on DIFFERENT SIMDs instead of queueing on one.  The kernel prologue checks that the four
 // roles are a permutation of 0..3 and falls back to the position in the workgroup otherwise (nd_assign_roles).  Measured, round 3:
-// config 5 11.87 -> 11.50 ms, tme_normal_2 16.95 -> 16.35 ms on real batches (-9..12 % when every workgroup runs the same
-// replicate in lock step).  An earlier form that re-read the role from LDS at every use gave the gain back (1 %).
+// config 5 11.87 -> 11.36 ms, tme_normal_2 16.95 -> 16.4 ms, B = 2048 35.4 -> 34.3 ms on real batches (-9..12 % when every
+// workgroup runs the same replicate in lock step).  An earlier form that re-read the role from LDS at every use gave the gain back (1 %).
 #ifndef MFS_ND_SIMD_ROLES
 #define MFS_ND_SIMD_ROLES 1
 #endif
