@@ -370,3 +370,28 @@ def test_bearing_likelihood_with_an_operator_table_transition():
     npt.assert_allclose(nell, rc[2], rtol=1e-6)
     npt.assert_allclose(means, rc[1], rtol=1e-6, atol=1e-9)
     assert parity.rel_err(cmss, rc[0], parity.natural_magnitude_nd(rc[0], mi)).max() <= 1e-6
+
+
+@pytest.mark.parametrize('family', ['tme_2', 'tme_normal_2'])
+def test_results_do_not_depend_on_the_batch_a_replicate_sits_in(family):
+    """The N-D kernel hands work to its four waves by a ROLE taken from the SIMD and wave slot a wave happens to sit on
+    (csrc/filternd_kernel.hpp nd_assign_roles), and runs two or three workgroups per CU depending on the tile: replicate 0 must
+    come out bit for bit the same whether it is filtered alone, with a few others, or in a batch that fills every CU three
+    times over."""
+    N, Tn = 5, 25
+    mi = generate_graded_lexico_multi_indices(2, 2 * N - 1)
+    inds = gram_and_hankel_indices_graded_lexico(N, 2)
+    from mfs_amd.multi_dims import ss_models
+    pdt, _, _, gs, pdrift, pdisp, _, ppmf, _ = ss_models.prey_predator(mi)
+    fns, sig = ((moments.sde_cond_moments_tme(pdrift, pdisp, pdt, 2), 'multi-index') if family == 'tme_2' else
+                (moments.sde_cond_moments_tme_normal(pdrift, pdisp, pdt, 2, mi), 'index'))
+    ys, _ = synth.prey_predator_batch(800, Tn, pdt, seed=3)
+    ref = None
+    for B in (1, 3, 513, 800):
+        c, m, n = filtering.moment_filter_nd_cms((fns[1], sig), fns[3], ppmf, ys[:B], (mi, inds), gs.cms, gs.mean)
+        assert np.all(np.isfinite(n))
+        if ref is None:
+            ref = (c[0].copy(), m[0].copy(), n[0])
+        npt.assert_array_equal(c[0], ref[0])
+        npt.assert_array_equal(m[0], ref[1])
+        assert n[0] == ref[2]
